@@ -1,0 +1,117 @@
+"""Pins the CPU oracle (oracle/vae_oracle.py) against fixtures generated from the REAL reference
+(oracle/make_golden.py, run in the build container).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import vae_oracle as O
+
+TINY = dict(Hq=32, Dz=16, Hd=64, L=3)
+REAL = dict(Hq=256, Dz=128, Hd=512, L=3)
+
+
+def _P(seed, dims, dtype=np.float64):
+    return {k: v.astype(dtype) for k, v in O.init_params(seed=seed, **dims).items()}
+
+
+@pytest.fixture(scope="module")
+def vocab(golden_dir):
+    with open(os.path.join(golden_dir, "vocab.json")) as f:
+        return json.load(f)
+
+
+def test_vocab_table(vocab):
+    assert O.ALL_SYMS == vocab["all_syms"]
+    assert (O.BOS, O.EOS, O.PAD, O.UNK) == (vocab["bos"], vocab["eos"], vocab["pad"], vocab["unk"])
+    assert O.N_VOCAB == 51
+
+
+def test_string2ids(vocab):
+    for s, ids in vocab["string2ids"]:
+        assert O.string2ids(s, True, True) == ids, s
+
+
+def test_ids2string(vocab):
+    for ids, s in vocab["ids2string"]:
+        if isinstance(s, dict):
+            with pytest.raises(IndexError):
+                O.ids2string(ids)
+        else:
+            assert O.ids2string(ids) == s, ids
+
+
+def test_collate_order(vocab):
+    got = O.collate(vocab["collate_in"])
+    assert [g.tolist() for g in got] == vocab["collate_ids"]
+
+
+def test_schedulers(vocab):
+    n, s, w0, w1 = vocab["kl_annealer"]["args"]
+    for i, v in enumerate(vocab["kl_annealer"]["values"]):
+        assert O.kl_weight(i, n, s, w0, w1) == pytest.approx(v, rel=1e-12)
+    sg = vocab["sgdr"]
+    tab = O.sgdr_lr_table(sg["base_lr"], len(sg["lrs"]) - 1, sg["lr_n_period"], sg["lr_n_mult"], sg["lr_end"])
+    np.testing.assert_allclose(tab, sg["lrs"], rtol=1e-12)
+
+
+def test_param_order(vocab):
+    P = O.init_params(0)
+    # reference names are relative to model.vae (ModuleList indices); compare shapes + count
+    names = O.param_order(P)
+    assert [list(P[n].shape) for n in names] == vocab["param_shapes"]
+    assert sum(P[n].size for n in names) == vocab["n_params"] == 4614236
+
+
+@pytest.mark.parametrize("tag,dims,seed,full", [("tiny", TINY, 1, True), ("real", REAL, 2, False)])
+def test_train_step_matches_reference(golden_dir, tag, dims, seed, full):
+    g = np.load(os.path.join(golden_dir, "train_%s.npz" % tag))
+    P = _P(seed, dims)
+    seqs = O.collate([str(s) for s in g["strings"]])
+    kl_w = float(g["kl_w"])
+    eps = g["eps"].astype(np.float64)
+    enc, dec = O.vae_forward(P, seqs, eps[0])
+    np.testing.assert_allclose(enc["z"], g["z"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(enc["mu"], g["mu"], rtol=2e-4, atol=2e-5)
+    assert enc["kl"] == pytest.approx(float(g["kl"]), rel=1e-5)
+    assert dec["recon"] == pytest.approx(float(g["recon"]), rel=1e-5)
+    np.testing.assert_allclose(dec["y"], g["y"], rtol=1e-3, atol=1e-4)
+    G, _ = O.vae_backward(P, enc, dec, g_kl=kl_w, g_recon=1.0)
+    for k in P:
+        if full:
+            ref = g["grad/" + k]
+            np.testing.assert_allclose(G[k], ref, rtol=1e-3, atol=1e-6 + 1e-4 * np.abs(ref).max(), err_msg=k)
+        else:
+            assert np.linalg.norm(G[k]) == pytest.approx(float(g["gnorm/" + k]), rel=1e-4), k
+            sl = G[k].reshape(-1)[:: max(1, G[k].size // 257)][:257]
+            ref = g["gslice/" + k]
+            np.testing.assert_allclose(sl, ref, rtol=1e-3, atol=1e-6 + 1e-4 * np.abs(ref).max(), err_msg=k)
+    # 3 steps of clip + Adam (vae_trainer.py:133-138)
+    st = O.adam_state(P)
+    for s in range(len(g["losses"])):
+        enc, dec = O.vae_forward(P, seqs, eps[s])
+        assert enc["kl"] == pytest.approx(g["losses"][s, 0], rel=2e-4)
+        assert dec["recon"] == pytest.approx(g["losses"][s, 1], rel=2e-4)
+        G, _ = O.vae_backward(P, enc, dec, g_kl=kl_w, g_recon=1.0)
+        G, total = O.clip_grad_norm(G, 50.0)
+        assert total == pytest.approx(g["gnorms"][s], rel=1e-3)
+        P = O.adam_step(P, G, st, lr=3e-4)
+    for k in P:
+        ref = g["pfinal/" + k]
+        got = P[k] if full else P[k].reshape(-1)[:: max(1, P[k].size // 257)][:257]
+        np.testing.assert_allclose(got, ref, rtol=1e-3, atol=2e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("tag,dims,seed", [("tiny", TINY, 3), ("real", REAL, 4), ("real_t07", REAL, 5)])
+def test_sampler_matches_reference(golden_dir, tag, dims, seed):
+    g = np.load(os.path.join(golden_dir, "sample_%s.npz" % tag))
+    P = _P(seed, dims)
+    P["decoder_fc.bias"] = P["decoder_fc.bias"].copy()
+    P["decoder_fc.bias"][O.EOS] += float(g["eos_bias"])
+    max_len = int(g["max_len"])
+    x, ep = O.sample_tokens(P, g["z"].astype(np.float64), g["u"], max_len=max_len, temp=float(g["temp"]))
+    assert O.tokens_to_strings(x, ep) == [str(s) for s in g["strings"]]
+    x, ep = O.sample_tokens(P, g["z"].astype(np.float64), None, max_len=max_len, temp=float(g["temp"]),
+                            multinomial=False)
+    assert O.tokens_to_strings(x, ep) == [str(s) for s in g["strings_argmax"]]
