@@ -1,0 +1,97 @@
+// Common device/host helpers for the POLYGON SMILES-VAE HIP library (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// ---- error plumbing (no C++ exceptions cross the C ABI) -----------------------------------
+extern thread_local char g_pg_err[512];
+#define PG_OK 0
+#define PG_ERR_ARG (-1)
+#define PG_ERR_HIP (-2)
+#define PG_ERR_UNSUPPORTED (-3)
+#define PG_ERR_WORKSPACE (-4)
+
+#define PG_FAIL(code, ...)                          \
+  do {                                              \
+    snprintf(g_pg_err, sizeof(g_pg_err), __VA_ARGS__); \
+    return (code);                                  \
+  } while (0)
+
+#define PG_CHECK_HIP(expr)                                                                   \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) PG_FAIL(PG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+#define PG_CHECK_LAUNCH() PG_CHECK_HIP(hipGetLastError())
+
+#define PG_REQUIRE(cond, ...)                 \
+  do {                                        \
+    if (!(cond)) PG_FAIL(PG_ERR_ARG, __VA_ARGS__); \
+  } while (0)
+
+// ---- scalar conversions -------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T x);
+template <> __device__ __forceinline__ float to_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+  // tanh(x) = 1 - 2/(exp(2x)+1); exact limits at +-inf, abs error ~1e-7
+  float e = __expf(2.0f * x);
+  return 1.0f - 2.0f / (e + 1.0f);
+}
+
+// ---- Philox4x32-10 (counter-based RNG; same stream whatever the launch geometry) ------------
+struct Philox4 {
+  uint32_t x, y, z, w;
+};
+__host__ __device__ __forceinline__ uint32_t pg_mulhi32(uint32_t a, uint32_t b) {
+  return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+}
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                          uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    uint32_t hi0 = pg_mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = pg_mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  Philox4 r = {c0, c1, c2, c3};
+  return r;
+}
+// uniform in [0,1) with 24 bits
+__host__ __device__ __forceinline__ float pg_u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// dropout keep/scale factor for element (layer, t, global batch row, column); p = drop probability
+__device__ __forceinline__ float dropout_scale(uint64_t seed, int layer, int t, int bglob, int col, float p, float inv_keep) {
+  Philox4 r = philox4x32_10((uint32_t)col, (uint32_t)bglob, (uint32_t)t, (uint32_t)layer, (uint32_t)seed,
+                            (uint32_t)(seed >> 32));
+  return pg_u01(r.x) >= p ? inv_keep : 0.0f;
+}
+
+// LDS requests above 64 KiB need the per-function opt-in (once per kernel per process).
+#define PG_LAUNCH_BIG_SMEM(kernel, grid, block, smem, stream, ...)                                                  \
+  do {                                                                                                               \
+    static bool _attr_done = false;                                                                                  \
+    if (!_attr_done && (smem) > 48 * 1024) {                                                                         \
+      PG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem))); \
+      _attr_done = true;                                                                                             \
+    }                                                                                                                \
+    hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                                              \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

@@ -1,0 +1,32 @@
+// Batched (non-recurrent) GEMM launchers built on the tile engines of pg_mma.h.
+#pragma once
+#include "pg_common.h"
+
+// Epilogue options of gemm_nt: C = alpha * A.B^T (+ bias[n]) (+ C32 if accumulate), optionally multiplied by the
+// inter-layer dropout mask of element (layer, row_t[m], row_b[m], n) (used by the dX GEMMs of the decoder backward).
+template <typename T> struct GemmEpi {
+  const float* bias = nullptr;       // [N]
+  float* C32 = nullptr;              // fp32 output (nullable)
+  T* Ct = nullptr;                   // operand-dtype output (nullable)
+  long ldc = 0;
+  int accumulate = 0;                // C32 += (needs C32)
+  float alpha = 1.0f;
+  const float* alpha_dev = nullptr;  // optional device scalar multiplied into alpha
+  // dropout mask (p_drop > 0 enables)
+  float p_drop = 0.0f;
+  unsigned long long seed = 0;
+  int layer = 0;
+  const int* row_t = nullptr;
+  const int* row_b = nullptr;
+  int b_mul = 1, b_add = 0;
+};
+
+// C[M,N] = A[M,K] . B[N,K]^T ; lda/ldb in elements, K % (16/sizeof(T)) == 0, 16-byte aligned rows.
+template <typename T>
+int launch_gemm_nt(const T* A, long lda, const T* B, long ldb, int M, int N, int K, const GemmEpi<T>& epi,
+                   hipStream_t stream);
+
+// C[M,N] (fp32, ldc) += alpha * A[R,M]^T . B[R,N]  (atomic accumulation, C must be initialised by the caller).
+template <typename T>
+int launch_gemm_tn(const T* A, long lda, const T* B, long ldb, int M, int N, int R, float* C, long ldc, float alpha,
+                   const float* alpha_dev, hipStream_t stream);

@@ -1,0 +1,298 @@
+// MFMA tile engines for gfx950 (64-wide waves, 32x32 MFMA tiles, LDS-staged operands).
+//
+//  * TileCfg / mma_mainloop_nt : C[m,n] += sum_k A[m,k] * B[n,k]   (both operands K-contiguous: activations x
+//    torch-layout weights).  Operands are staged global -> registers -> LDS in 16-byte chunks, double buffered,
+//    one barrier per K tile.  LDS rows are padded by 16 B so that the ds_read_b128 fragment reads are conflict free.
+//    bf16: v_mfma_f32_32x32x16_bf16 (fragment = 8 consecutive k in one 16-B chunk);
+//    f32 : v_mfma_f32_32x32x2_f32 x4 per 16-B chunk (lane half h supplies k = 4h..4h+3 of each 8-k step; A and B use
+//          the same assignment, so the contraction is complete and exact f32).
+//  * TileTN / mma_mainloop_tn : C[m,n] += sum_r A[r,m] * B[r,n]    (contraction over the ROW index of two row-major
+//    activations: weight gradients).  LDS keeps the tiles as they lie in memory ([k][m]); bf16 fragments are read
+//    with the gfx950 hardware-transposing ds_read_b64_tr_b16, f32 fragments with plain ds_read_b32.
+#pragma once
+#include "pg_common.h"
+
+template <typename T> struct MmaOp;
+template <> struct MmaOp<bf16_t> {
+  static __device__ __forceinline__ void run(f32x16& c, const uint4& a, const uint4& b) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct MmaOp<float> {
+  static __device__ __forceinline__ void run(f32x16& c, const uint4& a, const uint4& b) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+// Row-pointer functors: return the address of tile row `r` (K-contiguous) or nullptr for an out-of-range row.
+template <typename T> struct RowSrc {
+  const T* base;
+  long ld;
+  int row0, nrows;
+  __device__ __forceinline__ const T* operator()(int r) const {
+    int g = row0 + r;
+    return g < nrows ? base + (long)g * ld : nullptr;
+  }
+};
+// Weight rows of a GRU: tile row n = gate*BH + jj maps to weight row gate*H + j0 + jj.
+template <typename T> struct GateRowSrc {
+  const T* base;
+  long ld;
+  int H, j0, BH;
+  __device__ __forceinline__ const T* operator()(int n) const {
+    int g = n / BH, j = j0 + (n - g * BH);
+    return j < H ? base + (long)(g * H + j) * ld : nullptr;
+  }
+};
+
+template <typename T_, int BM_, int BN_, int BKC_, int WM_, int WN_, int NGATE_ = 1> struct TileCfg {
+  using T = T_;
+  static constexpr int BM = BM_, BN = BN_, BKC = BKC_, WM = WM_, WN = WN_, NGATE = NGATE_;
+  static constexpr int NTHREADS = 64 * WM * WN;
+  static constexpr int EPC = 16 / sizeof(T);   // elements per 16-byte chunk
+  static constexpr int BK = BKC * EPC;         // K elements per tile
+  static constexpr int ROWB = BKC * 16 + 16;   // padded LDS row bytes
+  static constexpr int WTM = BM / WM;          // rows per wave
+  static constexpr int TM = WTM / 32;
+  static constexpr int BNG = BN / NGATE;       // block columns per gate group
+  static constexpr int WTN = BNG / WN;         // columns per wave per gate group
+  static constexpr int TU = WTN / 32;
+  static constexpr int TN = TU * NGATE;
+  static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int SMEM_BYTES = 2 * STAGE_BYTES;
+  static constexpr int A_IT = (BM * BKC + NTHREADS - 1) / NTHREADS;
+  static constexpr int B_IT = (BN * BKC + NTHREADS - 1) / NTHREADS;
+  static_assert(BKC % 2 == 0, "BKC must be even");
+  static_assert(WTM % 32 == 0 && WTN % 32 == 0, "wave tile must be a multiple of 32");
+  // block-local column (within its gate group) of accumulator tile tn, lane column c
+  static __device__ __forceinline__ int col_in_group(int wn, int tn, int c) { return wn * WTN + (tn % TU) * 32 + c; }
+  static __device__ __forceinline__ int gate_of(int tn) { return tn / TU; }
+  static __device__ __forceinline__ int row_of(int wm, int tm, int reg, int lane) {
+    return wm * WTM + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+  }
+};
+
+// acc[tm][slot(tn)] += A-tile x B-tile over K.  SLOT_LAST: accumulator slot used by the LAST gate group (lets a
+// second pass route the n-gate to a separate accumulator).  Leaves the block synchronised (LDS reusable).
+template <class Cfg, int NACC, int SLOT_LAST, class ASrc, class BSrc>
+__device__ __forceinline__ void mma_mainloop_nt(f32x16 (&acc)[Cfg::TM][NACC], const ASrc& asrc, const BSrc& bsrc,
+                                                int K, char* smem) {
+  using T = typename Cfg::T;
+  constexpr int NT = Cfg::NTHREADS, BKC = Cfg::BKC, EPC = Cfg::EPC, ROWB = Cfg::ROWB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const T* pa[Cfg::A_IT];
+  const T* pb[Cfg::B_IT];
+  int oa[Cfg::A_IT], ob[Cfg::B_IT];
+#pragma unroll
+  for (int i = 0; i < Cfg::A_IT; ++i) {
+    int id = tid + i * NT;
+    int row = id / BKC, c = id % BKC;
+    bool ok = id < Cfg::BM * BKC;
+    pa[i] = ok ? asrc(row) : nullptr;
+    if (pa[i]) pa[i] += c * EPC;
+    oa[i] = ok ? row * ROWB + c * 16 : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < Cfg::B_IT; ++i) {
+    int id = tid + i * NT;
+    int row = id / BKC, c = id % BKC;
+    bool ok = id < Cfg::BN * BKC;
+    pb[i] = ok ? bsrc(row) : nullptr;
+    if (pb[i]) pb[i] += c * EPC;
+    ob[i] = ok ? row * ROWB + c * 16 : -1;
+  }
+  uint4 ra[Cfg::A_IT], rb[Cfg::B_IT];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  const int nk = (K + Cfg::BK - 1) / Cfg::BK;
+  auto gload = [&](int kt) {
+    const int k0 = kt * Cfg::BK;
+#pragma unroll
+    for (int i = 0; i < Cfg::A_IT; ++i) {
+      int c = (tid + i * NT) % BKC;
+      ra[i] = (pa[i] && k0 + c * EPC < K) ? *reinterpret_cast<const uint4*>(pa[i] + k0) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::B_IT; ++i) {
+      int c = (tid + i * NT) % BKC;
+      rb[i] = (pb[i] && k0 + c * EPC < K) ? *reinterpret_cast<const uint4*>(pb[i] + k0) : zero4;
+    }
+  };
+  auto sstore = [&](int buf) {
+    char* sa = smem + buf * Cfg::STAGE_BYTES;
+    char* sb = sa + Cfg::A_BYTES;
+#pragma unroll
+    for (int i = 0; i < Cfg::A_IT; ++i)
+      if (oa[i] >= 0) *reinterpret_cast<uint4*>(sa + oa[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < Cfg::B_IT; ++i)
+      if (ob[i] >= 0) *reinterpret_cast<uint4*>(sb + ob[i]) = rb[i];
+  };
+  const int lr = lane & 31, lh = lane >> 5;
+  auto compute = [&](int buf) {
+    const char* sa = smem + buf * Cfg::STAGE_BYTES;
+    const char* sb = sa + Cfg::A_BYTES;
+#pragma unroll
+    for (int s = 0; s < BKC / 2; ++s) {
+      uint4 fa[Cfg::TM], fb[Cfg::TN];
+#pragma unroll
+      for (int tm = 0; tm < Cfg::TM; ++tm)
+        fa[tm] = *reinterpret_cast<const uint4*>(sa + (wm * Cfg::WTM + tm * 32 + lr) * ROWB + (s * 2 + lh) * 16);
+#pragma unroll
+      for (int tn = 0; tn < Cfg::TN; ++tn) {
+        int brow = Cfg::gate_of(tn) * Cfg::BNG + Cfg::col_in_group(wn, tn, lr);
+        fb[tn] = *reinterpret_cast<const uint4*>(sb + brow * ROWB + (s * 2 + lh) * 16);
+      }
+#pragma unroll
+      for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < Cfg::TN; ++tn) {
+          constexpr int TU = Cfg::TU;
+          const int slot = (tn / TU == Cfg::NGATE - 1) ? SLOT_LAST * TU + tn % TU : tn;
+          MmaOp<T>::run(acc[tm][slot], fa[tm], fb[tn]);
+        }
+    }
+  };
+  if (nk > 0) {
+    gload(0);
+    sstore(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload(kt + 1);
+    compute(kt & 1);
+    if (kt + 1 < nk) sstore((kt + 1) & 1);
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// TN engine: contraction over rows.
+template <typename T_, int BM_, int BN_, int BKR_, int WM_, int WN_> struct TileTN {
+  using T = T_;
+  static constexpr int BM = BM_, BN = BN_, BKR = BKR_, WM = WM_, WN = WN_;
+  static constexpr int NTHREADS = 64 * WM * WN;
+  static constexpr int EPC = 16 / sizeof(T);
+  static constexpr int PADB = sizeof(T) == 2 ? 64 : 16;
+  static constexpr int ROWA = BM * (int)sizeof(T) + PADB, ROWBB = BN * (int)sizeof(T) + PADB;
+  static constexpr int WTM = BM / WM, WTN = BN / WN;
+  static constexpr int TM = WTM / 32, TN = WTN / 32;
+  static constexpr int A_BYTES = BKR * ROWA, B_BYTES = BKR * ROWBB;
+  static constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  static constexpr int SMEM_BYTES = 2 * STAGE_BYTES;
+  static constexpr int ACH = BM / EPC, BCH = BN / EPC;   // chunks per tile row
+  static constexpr int A_IT = (BKR * ACH + NTHREADS - 1) / NTHREADS;
+  static constexpr int B_IT = (BKR * BCH + NTHREADS - 1) / NTHREADS;
+  static_assert(BKR % 16 == 0, "BKR must be a multiple of 16");
+  static __device__ __forceinline__ int row_of(int wm, int tm, int reg, int lane) {
+    return wm * WTM + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+  }
+  static __device__ __forceinline__ int col_of(int wn, int tn, int lane) { return wn * WTN + tn * 32 + (lane & 31); }
+};
+
+template <typename T> struct TnFrag;
+template <> struct TnFrag<bf16_t> {
+  // fragment of a 32-row operand tile for one 16-k step, from an LDS image [k][m] (m contiguous)
+  static __device__ __forceinline__ uint4 load(const char* s, int rowbytes, int kbase, int mbase, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int k = kbase + 8 * (g >> 1) + q;
+    const int m = mbase + 16 * (g & 1) + 4 * p;
+    typedef __attribute__((address_space(3))) s16x4* lptr;
+    const char* a0 = s + k * rowbytes + m * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0 + 4 * rowbytes));
+    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
+  }
+  static constexpr int KSTEP = 16;
+  static __device__ __forceinline__ void mma(f32x16& c, const uint4& a, const uint4& b) { MmaOp<bf16_t>::run(c, a, b); }
+};
+template <> struct TnFrag<float> {
+  // one f32 per lane: A[m = lane&31][k = lane>>5] for a 2-k step
+  static __device__ __forceinline__ uint4 load(const char* s, int rowbytes, int kbase, int mbase, int lane) {
+    const float* p = reinterpret_cast<const float*>(s + (kbase + (lane >> 5)) * rowbytes) + mbase + (lane & 31);
+    const float* p2 = reinterpret_cast<const float*>(s + (kbase + 2 + (lane >> 5)) * rowbytes) + mbase + (lane & 31);
+    return make_uint4(__float_as_uint(*p), __float_as_uint(*p2), 0, 0);
+  }
+  static constexpr int KSTEP = 4;
+  static __device__ __forceinline__ void mma(f32x16& c, const uint4& a, const uint4& b) {
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+  }
+};
+
+// acc += A[r0:r1, m0:m0+BM]^T B[r0:r1, n0:n0+BN].  Columns >= Mtot / Ntot and rows >= r1 read as zero.
+template <class Cfg>
+__device__ __forceinline__ void mma_mainloop_tn(f32x16 (&acc)[Cfg::TM][Cfg::TN], const typename Cfg::T* A, long lda,
+                                                int m0, int Mtot, const typename Cfg::T* B, long ldb, int n0,
+                                                int Ntot, int r0, int r1, char* smem) {
+  using T = typename Cfg::T;
+  constexpr int NT = Cfg::NTHREADS, EPC = Cfg::EPC;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  uint4 ra[Cfg::A_IT], rb[Cfg::B_IT];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  const int nk = (r1 - r0 + Cfg::BKR - 1) / Cfg::BKR;
+  auto gload = [&](int kt) {
+    const int rr = r0 + kt * Cfg::BKR;
+#pragma unroll
+    for (int i = 0; i < Cfg::A_IT; ++i) {
+      int id = tid + i * NT, kr = id / Cfg::ACH, c = id % Cfg::ACH;
+      bool ok = id < Cfg::BKR * Cfg::ACH && rr + kr < r1 && m0 + c * EPC < Mtot;
+      ra[i] = ok ? *reinterpret_cast<const uint4*>(A + (long)(rr + kr) * lda + m0 + c * EPC) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::B_IT; ++i) {
+      int id = tid + i * NT, kr = id / Cfg::BCH, c = id % Cfg::BCH;
+      bool ok = id < Cfg::BKR * Cfg::BCH && rr + kr < r1 && n0 + c * EPC < Ntot;
+      rb[i] = ok ? *reinterpret_cast<const uint4*>(B + (long)(rr + kr) * ldb + n0 + c * EPC) : zero4;
+    }
+  };
+  auto sstore = [&](int buf) {
+    char* sa = smem + buf * Cfg::STAGE_BYTES;
+    char* sb = sa + Cfg::A_BYTES;
+#pragma unroll
+    for (int i = 0; i < Cfg::A_IT; ++i) {
+      int id = tid + i * NT, kr = id / Cfg::ACH, c = id % Cfg::ACH;
+      if (id < Cfg::BKR * Cfg::ACH) *reinterpret_cast<uint4*>(sa + kr * Cfg::ROWA + c * 16) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::B_IT; ++i) {
+      int id = tid + i * NT, kr = id / Cfg::BCH, c = id % Cfg::BCH;
+      if (id < Cfg::BKR * Cfg::BCH) *reinterpret_cast<uint4*>(sb + kr * Cfg::ROWBB + c * 16) = rb[i];
+    }
+  };
+  auto compute = [&](int buf) {
+    const char* sa = smem + buf * Cfg::STAGE_BYTES;
+    const char* sb = sa + Cfg::A_BYTES;
+#pragma unroll
+    for (int s = 0; s < Cfg::BKR / TnFrag<T>::KSTEP; ++s) {
+      uint4 fa[Cfg::TM], fb[Cfg::TN];
+#pragma unroll
+      for (int tm = 0; tm < Cfg::TM; ++tm)
+        fa[tm] = TnFrag<T>::load(sa, Cfg::ROWA, s * TnFrag<T>::KSTEP, wm * Cfg::WTM + tm * 32, lane);
+#pragma unroll
+      for (int tn = 0; tn < Cfg::TN; ++tn)
+        fb[tn] = TnFrag<T>::load(sb, Cfg::ROWBB, s * TnFrag<T>::KSTEP, wn * Cfg::WTN + tn * 32, lane);
+#pragma unroll
+      for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < Cfg::TN; ++tn) TnFrag<T>::mma(acc[tm][tn], fa[tm], fb[tn]);
+    }
+  };
+  if (nk > 0) {
+    gload(0);
+    sstore(0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload(kt + 1);
+    compute(kt & 1);
+    if (kt + 1 < nk) sstore((kt + 1) & 1);
+    __syncthreads();
+  }
+}
