@@ -1,9 +1,25 @@
-/* polygon_hip.h -- C ABI of libpolygon_hip.so (MI355X / gfx950 only).
+/* polygon_hip.h -- C ABI of libpolygon_hip.so: the MI355X (gfx950) hot path of POLYGON's SMILES VAE.
  *
- * Every entry point returns 0 on success or a negative PG_ERR_* code; pg_last_error() gives the
- * message of the calling thread's last failure.  All device pointers are raw HIP device pointers,
- * all work is enqueued on the caller's stream (a hipStream_t passed as void*), nothing is
- * allocated by the library and no C++ exception crosses the boundary.
+ * The reference (bpmunson/polygon) has no FFI boundary: its hot path is the Python class
+ * polygon/vae/vae_model.py:VAE whose arithmetic is delegated to stock torch modules.  Each entry
+ * point below replaces the torch call sites named in its comment (file:line relative to the
+ * reference root); the Python mirror of the reference API that binds them is polygon_amd/vae/.
+ *
+ * Conventions: every function returns 0 or a negative PG_ERR_* code; pg_last_error() returns the
+ * calling thread's last message.  Device pointers are raw HIP pointers; work is enqueued on the
+ * caller's stream (hipStream_t passed as void*); the library allocates nothing, keeps no global
+ * mutable state and performs no host synchronisation.  No C++ exception crosses the boundary.
+ *
+ * Parameters are ONE flat fp32 buffer in the order of model.vae.parameters()
+ * (vae_model.py:101-115, = optimiser order vae_trainer.py:99-100):
+ *   x_emb.weight[V,E]; encoder_rnn {weight_ih[3Hq,E], weight_hh[3Hq,Hq], bias_ih, bias_hh};
+ *   q_mu {weight[Dz,Hq], bias}; q_logvar {weight, bias}; decoder_lat {weight[Hd,Dz], bias};
+ *   decoder_rnn layer l {weight_ih[3Hd, l?Hd:E+Dz], weight_hh[3Hd,Hd], bias_ih, bias_hh} l=0..L-1;
+ *   decoder_fc {weight[V,Hd], bias}.   Gradients use the same layout and are ACCUMULATED (+=).
+ *
+ * Batches: tokens int32 [B,Tmax] row-major on the device, padded with pad; lengths int32 [B] on the
+ * HOST (bos..eos inclusive), sorted descending exactly as the reference collate does
+ * (vae_model.py:142-147); unsorted lengths are rejected like torch's pack_sequence.
  */
 #ifndef POLYGON_HIP_H
 #define POLYGON_HIP_H
@@ -15,20 +31,92 @@ extern "C" {
 
 #define PG_API __attribute__((visibility("default")))
 #define PG_VERSION 1
-#define PG_F32 0
-#define PG_BF16 1
+#define PG_F32 0  /* f32 operands on v_mfma_f32_32x32x2_f32 (exact f32) */
+#define PG_BF16 1 /* bf16 operands on v_mfma_f32_32x32x16_bf16, f32 accumulate, f32 state */
+#define PG_MAX_LAYERS 8
+#define PG_MAX_T 511  /* longest sequence (bos..eos) the packed scheduler accepts */
+#define PG_MAX_V 64   /* vocabulary limit of the softmax / cross-entropy / draw kernels */
+
+typedef struct pg_dims {
+  int V, E, Hq, Dz, Hd, L; /* vocab, embedding dim, encoder hidden, latent, decoder hidden, decoder layers */
+  int pad, bos, eos, unk;
+} pg_dims;
+
+/* data-parallel context of one call: rank r of G holds rows r, r+G, ... of the
+ * globally sorted batch.  kl_inv_batch = 1/B_global; ce_count = global number of non-pad targets
+ * (<= 0: use the locally counted value); b_mul/b_add map a local row to its global row
+ * (b*b_mul + b_add) so the dropout Philox stream is independent of G. */
+typedef struct pg_dp {
+  float kl_inv_batch;
+  float ce_count;
+  int b_mul, b_add;
+} pg_dp;
 
 PG_API int pg_version(void);
 PG_API const char* pg_last_error(void);
+PG_API long pg_param_count(const pg_dims* d);
+
+/* Derived ("shadow") weights: operand-dtype copies, transposes, the embedding x W_ih gather tables
+ * that replace nn.Embedding + the input half of the GRU (vae_model.py:224,253-256).  Rebuild after
+ * every parameter update. */
+PG_API size_t pg_shadow_bytes(const pg_dims* d, int dtype);
+PG_API int pg_prepare_weights(const pg_dims* d, int dtype, const float* params, void* shadow, void* stream);
+
+PG_API size_t pg_train_workspace_bytes(const pg_dims* d, int dtype, int B, long n_tokens);
+
+/* VAE.forward_encoder (vae_model.py:216-239): embedding gather + GRU encoder + q_mu/q_logvar +
+ * reparameterisation + KL.  eps [B,Dz] replaces torch.randn_like (NULL: z = mu).  Outputs (device):
+ * z [B,Dz], mu/logvar [B,Dz] (nullable), kl scalar (nullable).  save_for_backward keeps the BPTT
+ * state in the workspace for pg_encoder_bwd. */
+PG_API int pg_encoder_fwd(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes,
+                          int B, int Tmax, const int32_t* d_tokens, const int32_t* h_lengths, const float* eps,
+                          const pg_dp* dp, int save_for_backward, float* z, float* mu, float* logvar, float* kl,
+                          void* stream);
+
+/* VAE.forward_decoder (vae_model.py:241-275): z-conditioned L-layer GRU decoder (teacher forced),
+ * vocab projection, log-softmax, cross entropy with ignore_index=pad.  p_drop/seed: inter-layer
+ * dropout of nn.GRU in train mode (vae_model.py:90).  all_steps=1 also runs each row's last (eos
+ * input) step, which only matters when the logits are read back (return_y).  logits_packed (nullable)
+ * receives the device address of the packed [sum(steps), 64] fp32 logits inside the workspace. */
+PG_API int pg_decoder_fwd(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes,
+                          int B, int Tmax, const int32_t* d_tokens, const int32_t* h_lengths, const float* z,
+                          const pg_dp* dp, float p_drop, uint64_t seed, int all_steps, int save_for_backward,
+                          float* recon, float** logits_packed, void* stream);
+
+/* Hand-written BPTT of the two calls above (what loss.backward() does at vae_trainer.py:134).
+ * Upstream gradient of recon / kl = g_host * (*g_dev if g_dev else 1).  pg_decoder_bwd writes
+ * dz [B,Dz]; pg_encoder_bwd consumes it (NULL: no reconstruction path).  Both must see the same
+ * batch arguments and workspace as their forward call. */
+PG_API int pg_decoder_bwd(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes,
+                          int B, int Tmax, const int32_t* h_lengths, const pg_dp* dp, float p_drop, uint64_t seed,
+                          int all_steps, float g_host, const float* g_dev, float* grads, float* dz, void* stream);
+PG_API int pg_encoder_bwd(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes,
+                          int B, int Tmax, const int32_t* h_lengths, const pg_dp* dp, const float* dz, float g_host,
+                          const float* g_dev, float* grads, void* stream);
+
+/* clip_grad_norm_(params, max_norm) + Adam.step() (vae_trainer.py:136-138) over the flat buffers.
+ * scratch: >= 4 KiB device floats.  step = 1-based Adam step count.  max_norm <= 0 disables the
+ * clip.  gnorm (nullable) receives the pre-clip global L2 norm. */
+PG_API int pg_clip_adam(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int step, float lr,
+                        float beta1, float beta2, float eps, float max_norm, float* scratch, float* gnorm, void* stream);
+
+/* VAE.sample (vae_model.py:300-358): max_len-1 fused decode steps (3 GRU cells + vocab projection +
+ * softmax(y/temp) + inverse-CDF draw or argmax + eos bookkeeping), no early exit, as the reference.
+ * uniforms [max_len-1, n] (device) feed the draw of step i at uniforms[(i-1)*n + row]; NULL: Philox
+ * keyed by (seed, row_offset + row, step).  tokens uint8 [n,max_len], end_pads int32 [n]. */
+PG_API size_t pg_sample_workspace_bytes(const pg_dims* d, int dtype, int n);
+PG_API int pg_sample(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes, int n,
+                     int max_len, const float* z, const float* uniforms, uint64_t seed, long row_offset, float temp,
+                     int multinomial, uint8_t* tokens, int32_t* end_pads, void* stream);
 
 /* Kernel-level test hooks (no reference counterpart; they expose the MFMA tile engines that every
- * entry point below is built from, so tests can check them in isolation).
+ * entry point above is built from, so tests can check them in isolation).
  * pg_gemm_nt: C[M,N] = alpha * A[M,K] . B[N,K]^T (+bias[N]) (+C32 if accumulate) -> C32 (fp32) and/or Ct (dtype).
  * pg_gemm_tn: C[M,N] += alpha * A[R,M]^T . B[R,N]  (fp32 atomics into C). */
 PG_API int pg_gemm_nt(int dtype, const void* A, long lda, const void* B, long ldb, int M, int N, int K, const float* bias,
-               float* C32, void* Ct, long ldc, int accumulate, float alpha, void* stream);
+                      float* C32, void* Ct, long ldc, int accumulate, float alpha, void* stream);
 PG_API int pg_gemm_tn(int dtype, const void* A, long lda, const void* B, long ldb, int M, int N, int R, float* C, long ldc,
-               float alpha, void* stream);
+                      float alpha, void* stream);
 
 #ifdef __cplusplus
 }

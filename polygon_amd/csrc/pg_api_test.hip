@@ -2,11 +2,6 @@
 #include "../../include/polygon_hip.h"
 #include "pg_gemm.h"
 
-thread_local char g_pg_err[512] = {0};
-
-extern "C" const char* pg_last_error(void) { return g_pg_err; }
-extern "C" int pg_version(void) { return PG_VERSION; }
-
 template <typename T>
 static int gemm_nt_t(const void* A, long lda, const void* B, long ldb, int M, int N, int K, const float* bias,
                      float* C32, void* Ct, long ldc, int accumulate, float alpha, hipStream_t s) {

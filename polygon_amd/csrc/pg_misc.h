@@ -1,0 +1,281 @@
+// Elementwise / reduction / small kernels of the VAE hot path (HBM- or latency-bound work around the MFMA kernels).
+#pragma once
+#include "pg_common.h"
+#include "pg_layout.h"
+
+// ---- wave / block reductions (64-wide waves) ----------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- shadow weights ------------------------------------------------------------------------------
+struct CopyDesc {
+  long src_off;    // element offset into params (fp32)
+  size_t dst_off;  // byte offset into shadow
+  int rows, cols;  // source sub-matrix
+  int src_ld, dst_ld;
+  int transpose;   // dst[c*dst_ld + r] instead of dst[r*dst_ld + c]
+  int to_f32;      // destination is fp32 whatever T is
+};
+#define PG_MAX_COPY 48
+struct CopyTable {
+  int n;
+  CopyDesc d[PG_MAX_COPY];
+};
+
+template <typename T> __global__ void copy_table_kernel(const float* __restrict__ params, char* __restrict__ shadow, CopyTable tab) {
+  const CopyDesc d = tab.d[blockIdx.y];
+  const long total = (long)d.rows * d.cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    // iterate in DESTINATION order so that stores coalesce
+    int r, c;
+    if (d.transpose) { c = (int)(i / d.rows); r = (int)(i % d.rows); }
+    else { r = (int)(i / d.cols); c = (int)(i % d.cols); }
+    const float v = params[d.src_off + (long)r * d.src_ld + c];
+    const long o = d.transpose ? (long)c * d.dst_ld + r : (long)r * d.dst_ld + c;
+    if (d.to_f32) reinterpret_cast<float*>(shadow + d.dst_off)[o] = v;
+    else reinterpret_cast<T*>(shadow + d.dst_off)[o] = from_f32<T>(v);
+  }
+}
+
+// tab[v, g] = sum_e emb[v,e] * Wih[g, e] + b_ih[g] + (g < 2H ? b_hh[g] : 0)
+static __global__ void gi_table_kernel(const float* __restrict__ emb, int E, const float* __restrict__ Wih, int ldw,
+                                const float* __restrict__ bih, const float* __restrict__ bhh, int H, float* __restrict__ tab) {
+  const int v = blockIdx.y;
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= 3 * H) return;
+  float s = bih[g] + (g < 2 * H ? bhh[g] : 0.0f);
+  const float* e = emb + (long)v * E;
+  const float* w = Wih + (long)g * ldw;
+  for (int k = 0; k < E; ++k) s = fmaf(e[k], w[k], s);
+  tab[(long)v * 3 * H + g] = s;
+}
+static __global__ void bias_fold_kernel(const float* __restrict__ bih, const float* __restrict__ bhh, int H, float* __restrict__ out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < 3 * H) out[g] = bih[g] + (g < 2 * H ? bhh[g] : 0.0f);
+}
+
+// ---- packed batch ----------------------------------------------------------------------------------
+// mode 0: encoder (tok only).  mode 1: decoder (tok, target = next token, t, b) + offsets copy.
+static __global__ void build_packed_kernel(const int32_t* __restrict__ tokens, int B, int Tmax, int pad, Sched s, int mode,
+                                    int* __restrict__ tok, int* __restrict__ tgt, int* __restrict__ rt, int* __restrict__ rb,
+                                    int* __restrict__ off_out) {
+  const int t = blockIdx.x;
+  if (off_out && blockIdx.x == 0 && blockIdx.y == 0)
+    for (int i = threadIdx.x; i <= s.T + 1; i += blockDim.x) off_out[i] = s.off[i];
+  const int Bt = s.off[t + 1] - s.off[t];
+  const int b = blockIdx.y * blockDim.x + threadIdx.x;
+  if (b >= Bt) return;
+  const int r = s.off[t] + b;
+  tok[r] = tokens[(long)b * Tmax + t];
+  if (mode == 1) {
+    tgt[r] = (t + 1 < Tmax) ? tokens[(long)b * Tmax + t + 1] : pad;
+    rt[r] = t;
+    rb[r] = b;
+  }
+}
+
+template <typename T> __global__ void convert_kernel(const float* __restrict__ in, T* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = from_f32<T>(in[i]);
+}
+
+template <typename T> __global__ void onehot_kernel(const int* __restrict__ tok, long n, int Vp, T* __restrict__ out) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n * Vp; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / Vp;
+    const int v = (int)(i % Vp);
+    out[i] = from_f32<T>(tok[r] == v ? 1.0f : 0.0f);
+  }
+}
+
+// ---- encoder head: reparameterisation + KL (vae_model.py:232-236) ---------------------------------
+template <typename T>
+static __global__ void reparam_kl_kernel(const float* __restrict__ mulv, const float* __restrict__ eps, int B, int Dz,
+                                  float* __restrict__ z, T* __restrict__ z_op, float* __restrict__ mu_out,
+                                  float* __restrict__ lv_out, float* __restrict__ eps_save, float* __restrict__ kl_sum) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float term = 0.0f;
+  if (i < (long)B * Dz) {
+    const int b = (int)(i / Dz), k = (int)(i % Dz);
+    const float mu = mulv[(long)b * 2 * Dz + k], lv = mulv[(long)b * 2 * Dz + Dz + k];
+    const float e = eps ? eps[i] : 0.0f;
+    const float zz = mu + __expf(0.5f * lv) * e;
+    z[i] = zz;
+    if (z_op) z_op[i] = from_f32<T>(zz);
+    if (mu_out) mu_out[i] = mu;
+    if (lv_out) lv_out[i] = lv;
+    if (eps_save) eps_save[i] = e;
+    term = 0.5f * (__expf(lv) + mu * mu - 1.0f - lv);
+  }
+  term = wave_sum(term);
+  __shared__ float part[16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) part[wv] = term;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.0f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += part[w];
+    atomicAdd(kl_sum, s);
+  }
+}
+
+// dq[b, 0:Dz] = dmu, dq[b, Dz:2Dz] = dlogvar
+template <typename T>
+static __global__ void reparam_bwd_kernel(const float* __restrict__ mulv, const float* __restrict__ eps, const float* __restrict__ dz,
+                                   const float* __restrict__ scal, int B, int Dz, float* __restrict__ dq, T* __restrict__ dq_op) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * Dz) return;
+  const int b = (int)(i / Dz), k = (int)(i % Dz);
+  const float s_kl = scal[SC_GS_KL];
+  const float mu = mulv[(long)b * 2 * Dz + k], lv = mulv[(long)b * 2 * Dz + Dz + k];
+  const float g = dz ? dz[i] : 0.0f;
+  const float dmu = g + s_kl * mu;
+  const float dlv = g * eps[i] * 0.5f * __expf(0.5f * lv) + s_kl * 0.5f * (__expf(lv) - 1.0f);
+  const long o = (long)b * 2 * Dz + k;
+  dq[o] = dmu; dq[o + Dz] = dlv;
+  dq_op[o] = from_f32<T>(dmu); dq_op[o + Dz] = from_f32<T>(dlv);
+}
+
+// ---- cross entropy: one wave per packed row (V <= 64) ------------------------------------------------
+template <typename T>
+static __global__ void ce_kernel(const float* __restrict__ logits, const int* __restrict__ tgt, long N, int V, int Vp, int pad,
+                          T* __restrict__ dlogits, float* __restrict__ scal) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const long r = (long)blockIdx.x * (blockDim.x >> 6) + wv;
+  float loss = 0.0f, cnt = 0.0f;
+  if (r < N) {
+    const float x = lane < V ? logits[r * Vp + lane] : -INFINITY;
+    const float mx = wave_max(x);
+    const float e = lane < V ? __expf(x - mx) : 0.0f;
+    const float s = wave_sum(e);
+    const int tg = tgt[r];
+    const bool w = tg != pad;
+    const float xt = __shfl(x, tg < 64 ? tg : 0, 64);
+    if (w) { loss = __logf(s) + mx - xt; cnt = 1.0f; }
+    if (dlogits && lane < Vp) {
+      const float p = e / s;
+      dlogits[r * Vp + lane] = from_f32<T>(w && lane < V ? p - (lane == tg ? 1.0f : 0.0f) : 0.0f);
+    }
+  }
+  __shared__ float pl[16], pc[16];
+  if (lane == 0) { pl[wv] = loss; pc[wv] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.0f, c = 0.0f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { a += pl[w]; c += pc[w]; }
+    atomicAdd(scal + SC_CE_SUM, a);
+    atomicAdd(scal + SC_CE_CNT, c);
+  }
+}
+
+static __global__ void finalize_kl_kernel(float* scal, float inv_B, float* kl_out) {
+  scal[SC_KL] = scal[SC_KL_SUM] * inv_B;
+  if (kl_out) *kl_out = scal[SC_KL];
+}
+static __global__ void finalize_ce_kernel(float* scal, float count_override, float* recon_out) {
+  const float cnt = count_override > 0.0f ? count_override : scal[SC_CE_CNT];
+  scal[SC_INV_CNT] = 1.0f / cnt;
+  scal[SC_RECON] = scal[SC_CE_SUM] / cnt;
+  if (recon_out) *recon_out = scal[SC_RECON];
+}
+// slot = g_host * (*g_dev) * (which ? scal[which] : mul)
+static __global__ void grad_scale_kernel(float* scal, int slot, float g_host, const float* g_dev, int src_slot, float mul) {
+  scal[slot] = g_host * (g_dev ? *g_dev : 1.0f) * (src_slot >= 0 ? scal[src_slot] : mul);
+}
+
+// ---- column sums (bias gradients): out[c] += alpha * sum_r X[r, c] --------------------------------
+template <typename T>
+static __global__ void colsum_kernel(const T* __restrict__ X, long R, int C, long ld, long rows_per_block, float* __restrict__ out,
+                              float alpha, const float* __restrict__ alpha_dev) {
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  float s = 0.0f;
+  if (c < C)
+    for (long r = r0 + ry; r < r1; r += 4) s += to_f32<T>(X[r * ld + c]);
+  __shared__ float part[4][64];
+  part[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    const float a = alpha * (alpha_dev ? *alpha_dev : 1.0f);
+    atomicAdd(out + c, a * (part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx]));
+  }
+}
+
+// dzproj[b, c] = sum_{t : b < B_t} X[off[t] + b, c]     (gradient of the per-sequence z projection)
+template <typename T>
+static __global__ void rowseg_sum_kernel(const T* __restrict__ X, const int* __restrict__ off, int Tn, int C, float* __restrict__ out,
+                                  T* __restrict__ out_op) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.0f;
+  for (int t = 0; t < Tn; ++t) {
+    const int o = off[t];
+    if (b >= off[t + 1] - o) break;
+    s += to_f32<T>(X[(long)(o + b) * C + c]);
+  }
+  out[(long)b * C + c] = s;
+  out_op[(long)b * C + c] = from_f32<T>(s);
+}
+
+// one wave per output element: C[m*ldc + n] += alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]   (all fp32)
+static __global__ void small_gemm_kernel(const float* __restrict__ A, long sam, long sak, const float* __restrict__ Bm, long sbk,
+                                  long sbn, int M, int N, int K, float* __restrict__ C, long ldc, int skip_row) {
+  const int lane = threadIdx.x & 63;
+  const long w = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (w >= (long)M * N) return;
+  const int m = (int)(w / N), n = (int)(w % N);
+  if (m == skip_row) return;
+  float s = 0.0f;
+  for (int k = lane; k < K; k += 64) s = fmaf(A[m * sam + k * sak], Bm[k * sbk + n * sbn], s);
+  s = wave_sum(s);
+  if (lane == 0) C[m * ldc + n] += s;
+}
+
+// ---- optimiser: global-norm clip + Adam over the flat buffers -----------------------------------------
+#define PG_SUMSQ_BLOCKS 512
+static __global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ partial) {
+  float s = 0.0f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s = fmaf(g[i], g[i], s);
+  s = wave_sum(s);
+  __shared__ float part[16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) part[wv] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.0f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) a += part[w];
+    partial[blockIdx.x] = a;
+  }
+}
+static __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, const float* __restrict__ partial, int npartial, float max_norm, float step_size,
+                            float beta1, float beta2, float inv_sqrt_bc2, float eps, float* __restrict__ gnorm_out) {
+  __shared__ float red[256];
+  float s = 0.0f;
+  for (int i = threadIdx.x; i < npartial; i += blockDim.x) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float total = sqrtf(red[0]);
+  if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) *gnorm_out = total;
+  float coef = 1.0f;
+  if (max_norm > 0.0f) coef = fminf(max_norm / (total + 1e-6f), 1.0f);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i] * coef;
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+  }
+}

@@ -1,0 +1,518 @@
+// Entry points of the training path: shadow weights, encoder / decoder forward, BPTT, clip + Adam.
+#include <algorithm>
+#include <math.h>
+#include "pg_gemm.h"
+#include "pg_gru.h"
+#include "pg_layout.h"
+#include "pg_misc.h"
+
+thread_local char g_pg_err[512] = {0};
+
+extern "C" const char* pg_last_error(void) { return g_pg_err; }
+extern "C" int pg_version(void) { return PG_VERSION; }
+extern "C" long pg_param_count(const pg_dims* d) { return d ? param_offsets(d).total : -1; }
+
+#define PG_TRY(expr)            \
+  do {                          \
+    int _s = (expr);            \
+    if (_s != PG_OK) return _s; \
+  } while (0)
+
+template <typename T> static inline T* at(void* base, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(base) + off); }
+template <typename T> static inline const T* at(const void* base, size_t off) {
+  return reinterpret_cast<const T*>(static_cast<const char*>(base) + off);
+}
+static inline int ew_blocks(long n) { return (int)std::min<long>(cdiv(n, 256), 4096); }
+
+// ===================================================================================================
+// shadow weights
+// ===================================================================================================
+extern "C" size_t pg_shadow_bytes(const pg_dims* d, int dtype) {
+  if (check_dims(d, dtype) != PG_OK) return 0;
+  return shadow_offsets(d, dtype).total;
+}
+
+template <typename T>
+static int prepare_weights_t(const pg_dims* d, int dtype, const float* params, void* shadow, hipStream_t st) {
+  const ParamOff po = param_offsets(d);
+  const ShadowOff so = shadow_offsets(d, dtype);
+  const int Hq = d->Hq, Hd = d->Hd, Dz = d->Dz, E = d->E, V = d->V, Vp = vpad(d);
+  PG_CHECK_HIP(hipMemsetAsync(at<char>(shadow, so.fc_w), 0, so.tab_enc - so.fc_w, st));  // zero the padded fc rows
+  PG_CHECK_HIP(hipMemsetAsync(at<char>(shadow, so.fc_b), 0, (size_t)Vp * 4, st));
+  CopyTable tab;
+  tab.n = 0;
+  long maxel = 0;
+  auto add = [&](long src, size_t dst, int rows, int cols, int src_ld, int dst_ld, int tr, int f32) {
+    CopyDesc c = {src, dst, rows, cols, src_ld, dst_ld, tr, f32};
+    tab.d[tab.n++] = c;
+    if ((long)rows * cols > maxel) maxel = (long)rows * cols;
+  };
+  add(po.enc_whh, so.enc_whh, 3 * Hq, Hq, Hq, Hq, 0, 0);
+  add(po.enc_whh, so.enc_whhT, 3 * Hq, Hq, Hq, 3 * Hq, 1, 0);
+  add(po.qmu_w, so.wq, Dz, Hq, Hq, Hq, 0, 0);
+  add(po.qlv_w, so.wq + (size_t)Dz * Hq * sizeof(T), Dz, Hq, Hq, Hq, 0, 0);
+  add(po.qmu_w, so.wqT, Dz, Hq, Hq, 2 * Dz, 1, 0);
+  add(po.qlv_w, so.wqT + (size_t)Dz * sizeof(T), Dz, Hq, Hq, 2 * Dz, 1, 0);
+  add(po.qmu_b, so.bq, 1, Dz, Dz, Dz, 0, 1);
+  add(po.qlv_b, so.bq + (size_t)Dz * 4, 1, Dz, Dz, Dz, 0, 1);
+  add(po.lat_w, so.lat_w, Hd, Dz, Dz, Dz, 0, 0);
+  add(po.lat_w, so.lat_wT, Hd, Dz, Dz, Hd, 1, 0);
+  add(po.dec_wih[0] + E, so.wih0z, 3 * Hd, Dz, E + Dz, Dz, 0, 0);
+  add(po.dec_wih[0] + E, so.wih0zT, 3 * Hd, Dz, E + Dz, 3 * Hd, 1, 0);
+  for (int l = 0; l < d->L; ++l) {
+    add(po.dec_whh[l], so.whh[l], 3 * Hd, Hd, Hd, Hd, 0, 0);
+    add(po.dec_whh[l], so.whhT[l], 3 * Hd, Hd, Hd, 3 * Hd, 1, 0);
+    if (l > 0) {
+      add(po.dec_wih[l], so.wih[l], 3 * Hd, Hd, Hd, Hd, 0, 0);
+      add(po.dec_wih[l], so.wihT[l], 3 * Hd, Hd, Hd, 3 * Hd, 1, 0);
+    }
+  }
+  add(po.fc_w, so.fc_w, V, Hd, Hd, Hd, 0, 0);
+  add(po.fc_w, so.fc_wT, V, Hd, Hd, Vp, 1, 0);
+  add(po.fc_b, so.fc_b, 1, V, V, V, 0, 1);
+  PG_REQUIRE(tab.n <= PG_MAX_COPY, "copy table overflow");
+  hipLaunchKernelGGL(copy_table_kernel<T>, dim3(std::min<int>(cdiv(maxel, 256), 256), tab.n), dim3(256), 0, st, params,
+                     static_cast<char*>(shadow), tab);
+  PG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gi_table_kernel, dim3(cdiv(3 * Hq, 256), V), dim3(256), 0, st, params + po.x_emb, E, params + po.enc_wih, E,
+                     params + po.enc_bih, params + po.enc_bhh, Hq, at<float>(shadow, so.tab_enc));
+  PG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gi_table_kernel, dim3(cdiv(3 * Hd, 256), V), dim3(256), 0, st, params + po.x_emb, E, params + po.dec_wih[0],
+                     E + Dz, params + po.dec_bih[0], params + po.dec_bhh[0], Hd, at<float>(shadow, so.tab_dec));
+  PG_CHECK_LAUNCH();
+  for (int l = 1; l < d->L; ++l) {
+    hipLaunchKernelGGL(bias_fold_kernel, dim3(cdiv(3 * Hd, 256)), dim3(256), 0, st, params + po.dec_bih[l], params + po.dec_bhh[l],
+                       Hd, at<float>(shadow, so.bias_gi[l]));
+    PG_CHECK_LAUNCH();
+  }
+  return PG_OK;
+}
+
+extern "C" int pg_prepare_weights(const pg_dims* d, int dtype, const float* params, void* shadow, void* stream) {
+  PG_TRY(check_dims(d, dtype));
+  PG_REQUIRE(params && shadow, "pg_prepare_weights: NULL buffer");
+  return dtype == PG_BF16 ? prepare_weights_t<bf16_t>(d, dtype, params, shadow, (hipStream_t)stream)
+                          : prepare_weights_t<float>(d, dtype, params, shadow, (hipStream_t)stream);
+}
+
+// ===================================================================================================
+// workspace
+// ===================================================================================================
+extern "C" size_t pg_train_workspace_bytes(const pg_dims* d, int dtype, int B, long n_tokens) {
+  if (check_dims(d, dtype) != PG_OK || B < 1 || n_tokens < B) return 0;
+  return train_ws_layout(d, dtype, B, n_tokens, n_tokens).total;
+}
+
+static inline long sum_len(const int32_t* l, int B) {
+  long s = 0;
+  for (int i = 0; i < B; ++i) s += l[i];
+  return s;
+}
+
+template <typename T> static int convert_to(const float* in, T* out, long n, hipStream_t st) {
+  hipLaunchKernelGGL(convert_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, st, in, out, n);
+  PG_CHECK_LAUNCH();
+  return PG_OK;
+}
+template <typename T>
+static int colsum(const T* X, long R, int C, long ld, float* out, float alpha, const float* alpha_dev, hipStream_t st) {
+  if (R <= 0) return PG_OK;
+  const int ysplit = (int)std::max<long>(1, std::min<long>(cdiv(R, 64), 128));
+  const long rpb = cdiv(R, ysplit);
+  hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(C, 64), cdiv(R, rpb)), dim3(256), 0, st, X, R, C, ld, rpb, out, alpha, alpha_dev);
+  PG_CHECK_LAUNCH();
+  return PG_OK;
+}
+static int small_gemm(const float* A, long sam, long sak, const float* Bm, long sbk, long sbn, int M, int N, int K, float* C,
+                      long ldc, int skip_row, hipStream_t st) {
+  hipLaunchKernelGGL(small_gemm_kernel, dim3(cdiv((long)M * N, 4)), dim3(256), 0, st, A, sam, sak, Bm, sbk, sbn, M, N, K, C, ldc,
+                     skip_row);
+  PG_CHECK_LAUNCH();
+  return PG_OK;
+}
+
+// ===================================================================================================
+// encoder forward
+// ===================================================================================================
+template <typename T>
+static int encoder_fwd_t(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes, int B,
+                         int Tmax, const int32_t* d_tokens, const int32_t* lens, const float* eps, const pg_dp* dp, int save,
+                         float* z, float* mu, float* logvar, float* kl, hipStream_t st) {
+  const ParamOff po = param_offsets(d);
+  const ShadowOff so = shadow_offsets(d, dtype);
+  Sched se;
+  PG_TRY(make_sched(lens, B, Tmax, 0, &se));
+  const long Ne = se.off[se.T];
+  const TrainWs w = train_ws_layout(d, dtype, B, Ne, Ne);
+  PG_REQUIRE(ws_bytes >= w.total, "encoder_fwd: workspace too small (%zu < %zu)", ws_bytes, w.total);
+  const int Hq = d->Hq, Dz = d->Dz;
+  hipLaunchKernelGGL(build_packed_kernel, dim3(se.T, cdiv(B, 256)), dim3(256), 0, st, d_tokens, B, Tmax, d->pad, se, 0,
+                     at<int>(ws, w.enc_tok), (int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr);
+  PG_CHECK_LAUNCH();
+  float* scal = at<float>(ws, w.scalars);
+  PG_CHECK_HIP(hipMemsetAsync(scal + SC_KL_SUM, 0, 2 * sizeof(float), st));
+  float* carry = at<float>(ws, w.e_carry);
+  for (int t = 0; t < se.T; ++t) {
+    GruFwdArgs<T> a;
+    a.rows = sched_B(se, t); a.H = Hq;
+    if (t > 0) { a.hprev_op = at<T>(ws, w.e_hop[(t - 1) & 1]); a.hprev32 = carry; }
+    a.Whh = at<T>(shadow, so.enc_whh);
+    a.bhn = params + po.enc_bhh + 2 * Hq;
+    a.gi_mode = PG_GI_TABLE;
+    a.table = at<float>(shadow, so.tab_enc);
+    a.tok = at<int>(ws, w.enc_tok) + se.off[t];
+    a.h_op = at<T>(ws, w.e_hop[t & 1]);
+    a.h32 = carry;
+    if (save) {
+      const long o = (long)se.off[t] * Hq;
+      a.sv_r = at<T>(ws, w.e_sv[0]) + o; a.sv_z = at<T>(ws, w.e_sv[1]) + o; a.sv_n = at<T>(ws, w.e_sv[2]) + o;
+      a.sv_hn = at<T>(ws, w.e_sv[3]) + o; a.sv_hprev = at<T>(ws, w.e_sv[4]) + o;
+    }
+    PG_TRY(launch_gru_fwd<T>(a, st));
+  }
+  // q_mu | q_logvar on the final states (each row's own last step: the carry is updated in place)
+  PG_TRY(convert_to<T>(carry, at<T>(ws, w.e_hfin_op), (long)B * Hq, st));
+  GemmEpi<T> e;
+  e.bias = at<float>(shadow, so.bq); e.C32 = at<float>(ws, w.e_mulv); e.ldc = 2 * Dz;
+  PG_TRY(launch_gemm_nt<T>(at<T>(ws, w.e_hfin_op), Hq, at<T>(shadow, so.wq), Hq, B, 2 * Dz, Hq, e, st));
+  hipLaunchKernelGGL(reparam_kl_kernel<T>, dim3(cdiv((long)B * Dz, 256)), dim3(256), 0, st, at<float>(ws, w.e_mulv), eps, B, Dz, z,
+                     at<T>(ws, w.e_zop), mu, logvar, save ? at<float>(ws, w.e_eps) : (float*)nullptr, scal + SC_KL_SUM);
+  PG_CHECK_LAUNCH();
+  const float inv_B = (dp && dp->kl_inv_batch > 0.0f) ? dp->kl_inv_batch : 1.0f / (float)B;
+  hipLaunchKernelGGL(finalize_kl_kernel, dim3(1), dim3(1), 0, st, scal, inv_B, kl);
+  PG_CHECK_LAUNCH();
+  return PG_OK;
+}
+
+extern "C" int pg_encoder_fwd(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes,
+                              int B, int Tmax, const int32_t* d_tokens, const int32_t* h_lengths, const float* eps,
+                              const pg_dp* dp, int save_for_backward, float* z, float* mu, float* logvar, float* kl,
+                              void* stream) {
+  PG_TRY(check_dims(d, dtype));
+  PG_REQUIRE(params && shadow && ws && d_tokens && z, "pg_encoder_fwd: NULL buffer");
+  return dtype == PG_BF16
+             ? encoder_fwd_t<bf16_t>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, d_tokens, h_lengths, eps, dp,
+                                     save_for_backward, z, mu, logvar, kl, (hipStream_t)stream)
+             : encoder_fwd_t<float>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, d_tokens, h_lengths, eps, dp,
+                                    save_for_backward, z, mu, logvar, kl, (hipStream_t)stream);
+}
+
+// ===================================================================================================
+// decoder forward
+// ===================================================================================================
+template <typename T>
+static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes, int B,
+                         int Tmax, const int32_t* d_tokens, const int32_t* lens, const float* z, const pg_dp* dp, float p_drop,
+                         uint64_t seed, int all_steps, int save, float* recon, float** logits_packed, hipStream_t st) {
+  const ParamOff po = param_offsets(d);
+  const ShadowOff so = shadow_offsets(d, dtype);
+  Sched sd;
+  PG_TRY(make_sched(lens, B, Tmax, all_steps ? 0 : 1, &sd));
+  PG_REQUIRE(sd.T >= 1, "decoder_fwd: sequences of length 1 have no decoder step");
+  const long Ne = sum_len(lens, B), Nd = sd.off[sd.T];
+  const TrainWs w = train_ws_layout(d, dtype, B, Ne, Ne);
+  PG_REQUIRE(ws_bytes >= w.total, "decoder_fwd: workspace too small (%zu < %zu)", ws_bytes, w.total);
+  PG_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "decoder_fwd: dropout %f outside [0,1)", p_drop);
+  const int Hd = d->Hd, Dz = d->Dz, L = d->L, Vp = vpad(d);
+  const int b_mul = dp ? dp->b_mul : 1, b_add = dp ? dp->b_add : 0;
+  hipLaunchKernelGGL(build_packed_kernel, dim3(sd.T, cdiv(B, 256)), dim3(256), 0, st, d_tokens, B, Tmax, d->pad, sd, 1,
+                     at<int>(ws, w.dec_tok), at<int>(ws, w.dec_tgt), at<int>(ws, w.dec_t), at<int>(ws, w.dec_b),
+                     at<int>(ws, w.dec_off));
+  PG_CHECK_LAUNCH();
+  float* scal = at<float>(ws, w.scalars);
+  PG_CHECK_HIP(hipMemsetAsync(scal + SC_CE_SUM, 0, 2 * sizeof(float), st));
+  T* z_op = at<T>(ws, w.d_zop);
+  PG_TRY(convert_to<T>(z, z_op, (long)B * Dz, st));
+  {  // per-sequence half of the layer-0 input projection: W_ih0[:, E:] z
+    GemmEpi<T> e;
+    e.C32 = at<float>(ws, w.d_zproj); e.ldc = 3 * Hd;
+    PG_TRY(launch_gemm_nt<T>(z_op, Dz, at<T>(shadow, so.wih0z), Dz, B, 3 * Hd, Dz, e, st));
+  }
+  {  // h0 = decoder_lat(z)
+    GemmEpi<T> e;
+    e.bias = params + po.lat_b; e.C32 = at<float>(ws, w.d_h0_32); e.Ct = at<T>(ws, w.d_h0_op); e.ldc = Hd;
+    PG_TRY(launch_gemm_nt<T>(z_op, Dz, at<T>(shadow, so.lat_w), Dz, B, Hd, Dz, e, st));
+  }
+  const bool drop = p_drop > 0.0f;
+  for (int l = 0; l < L; ++l) {
+    float* carry = at<float>(ws, w.d_carry[l]);
+    PG_CHECK_HIP(hipMemcpyAsync(carry, at<float>(ws, w.d_h0_32), (size_t)B * Hd * 4, hipMemcpyDeviceToDevice, st));
+    T* hseq = at<T>(ws, w.d_hseq[l]);
+    if (l > 0) {  // batched input projection of the whole layer (non-recurrent)
+      const T* X = drop ? at<T>(ws, w.d_hdrop[l - 1]) : at<T>(ws, w.d_hseq[l - 1]);
+      GemmEpi<T> e;
+      e.bias = at<float>(shadow, so.bias_gi[l]); e.C32 = at<float>(ws, w.d_gi); e.ldc = 3 * Hd;
+      PG_TRY(launch_gemm_nt<T>(X, Hd, at<T>(shadow, so.wih[l]), Hd, (int)Nd, 3 * Hd, Hd, e, st));
+    }
+    for (int t = 0; t < sd.T; ++t) {
+      GruFwdArgs<T> a;
+      a.rows = sched_B(sd, t); a.H = Hd;
+      a.hprev_op = t == 0 ? at<T>(ws, w.d_h0_op) : hseq + (long)sd.off[t - 1] * Hd;
+      a.hprev32 = carry;
+      a.Whh = at<T>(shadow, so.whh[l]);
+      a.bhn = params + po.dec_bhh[l] + 2 * Hd;
+      if (l == 0) {
+        a.gi_mode = PG_GI_TABLE;
+        a.table = at<float>(shadow, so.tab_dec);
+        a.tok = at<int>(ws, w.dec_tok) + sd.off[t];
+        a.zproj = at<float>(ws, w.d_zproj);
+      } else {
+        a.gi_mode = PG_GI_ARRAY;
+        a.gi = at<float>(ws, w.d_gi) + (long)sd.off[t] * 3 * Hd;
+      }
+      const long o = (long)sd.off[t] * Hd;
+      a.h_op = hseq + o;
+      a.h32 = carry;
+      if (save) {
+        a.sv_r = at<T>(ws, w.d_sv[l][0]) + o; a.sv_z = at<T>(ws, w.d_sv[l][1]) + o; a.sv_n = at<T>(ws, w.d_sv[l][2]) + o;
+        a.sv_hn = at<T>(ws, w.d_sv[l][3]) + o; a.sv_hprev = at<T>(ws, w.d_sv[l][4]) + o;
+      }
+      if (drop && l < L - 1) {
+        a.h_drop = at<T>(ws, w.d_hdrop[l]) + o;
+        a.p_drop = p_drop; a.seed = seed; a.layer = l; a.t = t; a.b_mul = b_mul; a.b_add = b_add;
+      }
+      PG_TRY(launch_gru_fwd<T>(a, st));
+    }
+  }
+  {  // vocab projection
+    GemmEpi<T> e;
+    e.bias = at<float>(shadow, so.fc_b); e.C32 = at<float>(ws, w.d_logits); e.ldc = Vp;
+    PG_TRY(launch_gemm_nt<T>(at<T>(ws, w.d_hseq[L - 1]), Hd, at<T>(shadow, so.fc_w), Hd, (int)Nd, Vp, Hd, e, st));
+  }
+  hipLaunchKernelGGL(ce_kernel<T>, dim3(cdiv(Nd, 4)), dim3(256), 0, st, at<float>(ws, w.d_logits), at<int>(ws, w.dec_tgt), Nd,
+                     d->V, Vp, d->pad, save ? at<T>(ws, w.d_dlogits) : (T*)nullptr, scal);
+  PG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(finalize_ce_kernel, dim3(1), dim3(1), 0, st, scal, dp ? dp->ce_count : 0.0f, recon);
+  PG_CHECK_LAUNCH();
+  if (logits_packed) *logits_packed = at<float>(ws, w.d_logits);
+  return PG_OK;
+}
+
+extern "C" int pg_decoder_fwd(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes,
+                              int B, int Tmax, const int32_t* d_tokens, const int32_t* h_lengths, const float* z,
+                              const pg_dp* dp, float p_drop, uint64_t seed, int all_steps, int save_for_backward,
+                              float* recon, float** logits_packed, void* stream) {
+  PG_TRY(check_dims(d, dtype));
+  PG_REQUIRE(params && shadow && ws && d_tokens && z, "pg_decoder_fwd: NULL buffer");
+  return dtype == PG_BF16
+             ? decoder_fwd_t<bf16_t>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, d_tokens, h_lengths, z, dp, p_drop, seed,
+                                     all_steps, save_for_backward, recon, logits_packed, (hipStream_t)stream)
+             : decoder_fwd_t<float>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, d_tokens, h_lengths, z, dp, p_drop, seed,
+                                    all_steps, save_for_backward, recon, logits_packed, (hipStream_t)stream);
+}
+
+// ===================================================================================================
+// decoder backward (BPTT)
+// ===================================================================================================
+template <typename T>
+static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes, int B,
+                         int Tmax, const int32_t* lens, const pg_dp* dp, float p_drop, uint64_t seed, int all_steps,
+                         float g_host, const float* g_dev, float* grads, float* dz, hipStream_t st) {
+  const ParamOff po = param_offsets(d);
+  const ShadowOff so = shadow_offsets(d, dtype);
+  Sched sd;
+  PG_TRY(make_sched(lens, B, Tmax, all_steps ? 0 : 1, &sd));
+  const long Ne = sum_len(lens, B), Nd = sd.off[sd.T];
+  const TrainWs w = train_ws_layout(d, dtype, B, Ne, Ne);
+  PG_REQUIRE(ws_bytes >= w.total, "decoder_bwd: workspace too small (%zu < %zu)", ws_bytes, w.total);
+  const int Hd = d->Hd, Dz = d->Dz, L = d->L, Vp = vpad(d), V = d->V, E = d->E;
+  const int b_mul = dp ? dp->b_mul : 1, b_add = dp ? dp->b_add : 0;
+  float* scal = at<float>(ws, w.scalars);
+  hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, st, scal, (int)SC_GS_CE, g_host, g_dev, (int)SC_INV_CNT, 1.0f);
+  PG_CHECK_LAUNCH();
+  const float* s_ce = scal + SC_GS_CE;
+  T* dlog = at<T>(ws, w.d_dlogits);
+  const T* top = at<T>(ws, w.d_hseq[L - 1]);
+  // decoder_fc
+  PG_TRY(launch_gemm_tn<T>(dlog, Vp, top, Hd, V, Hd, (int)Nd, grads + po.fc_w, Hd, 1.0f, s_ce, st));
+  PG_TRY(colsum<T>(dlog, Nd, V, Vp, grads + po.fc_b, 1.0f, s_ce, st));
+  float* dout = at<float>(ws, w.b_dout);
+  {
+    GemmEpi<T> e;
+    e.C32 = dout; e.ldc = Hd; e.alpha_dev = s_ce;
+    PG_TRY(launch_gemm_nt<T>(dlog, Vp, at<T>(shadow, so.fc_wT), Vp, (int)Nd, Hd, Vp, e, st));
+  }
+  T* dGI = at<T>(ws, w.b_dGI);
+  T* dGH = at<T>(ws, w.b_dGH);
+  float* dh0 = at<float>(ws, w.b_dh0);
+  const bool drop = p_drop > 0.0f;
+  for (int l = L - 1; l >= 0; --l) {
+    for (int t = sd.T - 1; t >= -1; --t) {
+      GruBwdArgs<T> a;
+      a.H = Hd;
+      a.rows_in = (t + 1 < sd.T) ? sched_B(sd, t + 1) : 0;
+      a.dGH_in = dGH + (long)sd.off[t + 1 < sd.T ? t + 1 : 0] * 3 * Hd;
+      a.WhhT = at<T>(shadow, so.whhT[l]);
+      a.dhz_in = at<float>(ws, w.b_dhz[(t + 1) & 1]);
+      if (t >= 0) {
+        const long o = (long)sd.off[t] * Hd;
+        a.rows_out = sched_B(sd, t);
+        a.dout = dout + o;
+        a.sv_r = at<T>(ws, w.d_sv[l][0]) + o; a.sv_z = at<T>(ws, w.d_sv[l][1]) + o; a.sv_n = at<T>(ws, w.d_sv[l][2]) + o;
+        a.sv_hn = at<T>(ws, w.d_sv[l][3]) + o; a.sv_hprev = at<T>(ws, w.d_sv[l][4]) + o;
+        a.dGI = dGI + o * 3; a.dGH = dGH + o * 3;
+        a.dhz_out = at<float>(ws, w.b_dhz[t & 1]);
+      } else {  // gradient of h0 (shared by all layers)
+        a.rows_out = a.rows_in;
+        a.final_step = 1;
+        a.dh0 = dh0;
+        a.dh0_accumulate = (l != L - 1);
+      }
+      PG_TRY(launch_gru_bwd<T>(a, st));
+    }
+    // weight / bias gradients of the layer (batched over all packed rows)
+    PG_TRY(launch_gemm_tn<T>(dGH, 3 * Hd, at<T>(ws, w.d_sv[l][4]), Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_whh[l], Hd, 1.0f,
+                             nullptr, st));
+    PG_TRY(colsum<T>(dGH, Nd, 3 * Hd, 3 * Hd, grads + po.dec_bhh[l], 1.0f, nullptr, st));
+    PG_TRY(colsum<T>(dGI, Nd, 3 * Hd, 3 * Hd, grads + po.dec_bih[l], 1.0f, nullptr, st));
+    if (l > 0) {
+      const T* X = drop ? at<T>(ws, w.d_hdrop[l - 1]) : at<T>(ws, w.d_hseq[l - 1]);
+      PG_TRY(launch_gemm_tn<T>(dGI, 3 * Hd, X, Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_wih[l], Hd, 1.0f, nullptr, st));
+      GemmEpi<T> e;  // gradient wrt the layer below's outputs (through its dropout mask)
+      e.C32 = dout; e.ldc = Hd;
+      if (drop) {
+        e.p_drop = p_drop; e.seed = seed; e.layer = l - 1; e.row_t = at<int>(ws, w.dec_t); e.row_b = at<int>(ws, w.dec_b);
+        e.b_mul = b_mul; e.b_add = b_add;
+      }
+      PG_TRY(launch_gemm_nt<T>(dGI, 3 * Hd, at<T>(shadow, so.wihT[l]), 3 * Hd, (int)Nd, Hd, 3 * Hd, e, st));
+    } else {
+      // layer 0 input = [x_emb[token] ; z]: token half through the gather table, z half per sequence
+      T* oh = at<T>(ws, w.b_onehot);
+      float* dT = at<float>(ws, w.b_dT);
+      hipLaunchKernelGGL(onehot_kernel<T>, dim3(ew_blocks(Nd * Vp)), dim3(256), 0, st, at<int>(ws, w.dec_tok), Nd, Vp, oh);
+      PG_CHECK_LAUNCH();
+      PG_CHECK_HIP(hipMemsetAsync(dT, 0, (size_t)Vp * 3 * Hd * 4, st));
+      PG_TRY(launch_gemm_tn<T>(oh, Vp, dGI, 3 * Hd, Vp, 3 * Hd, (int)Nd, dT, 3 * Hd, 1.0f, nullptr, st));
+      // d x_emb[v,e] += sum_g dT[v,g] W_ih0[g,e] ; d W_ih0[g,e] += sum_v dT[v,g] x_emb[v,e]
+      PG_TRY(small_gemm(dT, 3 * Hd, 1, params + po.dec_wih[0], E + Dz, 1, V, E, 3 * Hd, grads + po.x_emb, E, d->pad, st));
+      PG_TRY(small_gemm(dT, 1, 3 * Hd, params + po.x_emb, E, 1, 3 * Hd, E, V, grads + po.dec_wih[0], E + Dz, -1, st));
+      float* dzp = at<float>(ws, w.b_dzproj);
+      T* dzp_op = at<T>(ws, w.b_dzproj_op);
+      hipLaunchKernelGGL(rowseg_sum_kernel<T>, dim3(cdiv(3 * Hd, 256), B), dim3(256), 0, st, dGI, at<int>(ws, w.dec_off), sd.T,
+                         3 * Hd, dzp, dzp_op);
+      PG_CHECK_LAUNCH();
+      PG_TRY(launch_gemm_tn<T>(dzp_op, 3 * Hd, at<T>(ws, w.d_zop), Dz, 3 * Hd, Dz, B, grads + po.dec_wih[0] + E, E + Dz, 1.0f,
+                               nullptr, st));
+      GemmEpi<T> e;
+      e.C32 = dz; e.ldc = Dz;
+      PG_TRY(launch_gemm_nt<T>(dzp_op, 3 * Hd, at<T>(shadow, so.wih0zT), 3 * Hd, B, Dz, 3 * Hd, e, st));
+    }
+  }
+  // decoder_lat: h0 = W z + b feeds every layer
+  T* dh0_op = at<T>(ws, w.b_dh0_op);
+  PG_TRY(convert_to<T>(dh0, dh0_op, (long)B * Hd, st));
+  PG_TRY(launch_gemm_tn<T>(dh0_op, Hd, at<T>(ws, w.d_zop), Dz, Hd, Dz, B, grads + po.lat_w, Dz, 1.0f, nullptr, st));
+  PG_TRY(colsum<T>(dh0_op, B, Hd, Hd, grads + po.lat_b, 1.0f, nullptr, st));
+  {
+    GemmEpi<T> e;
+    e.C32 = dz; e.ldc = Dz; e.accumulate = 1;
+    PG_TRY(launch_gemm_nt<T>(dh0_op, Hd, at<T>(shadow, so.lat_wT), Hd, B, Dz, Hd, e, st));
+  }
+  return PG_OK;
+}
+
+extern "C" int pg_decoder_bwd(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes,
+                              int B, int Tmax, const int32_t* h_lengths, const pg_dp* dp, float p_drop, uint64_t seed,
+                              int all_steps, float g_host, const float* g_dev, float* grads, float* dz, void* stream) {
+  PG_TRY(check_dims(d, dtype));
+  PG_REQUIRE(params && shadow && ws && grads && dz, "pg_decoder_bwd: NULL buffer");
+  return dtype == PG_BF16 ? decoder_bwd_t<bf16_t>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, h_lengths, dp, p_drop, seed,
+                                                  all_steps, g_host, g_dev, grads, dz, (hipStream_t)stream)
+                          : decoder_bwd_t<float>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, h_lengths, dp, p_drop, seed,
+                                                 all_steps, g_host, g_dev, grads, dz, (hipStream_t)stream);
+}
+
+// ===================================================================================================
+// encoder backward (BPTT)
+// ===================================================================================================
+template <typename T>
+static int encoder_bwd_t(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes, int B,
+                         int Tmax, const int32_t* lens, const pg_dp* dp, const float* dz, float g_host, const float* g_dev,
+                         float* grads, hipStream_t st) {
+  const ParamOff po = param_offsets(d);
+  const ShadowOff so = shadow_offsets(d, dtype);
+  Sched se;
+  PG_TRY(make_sched(lens, B, Tmax, 0, &se));
+  const long Ne = se.off[se.T];
+  const TrainWs w = train_ws_layout(d, dtype, B, Ne, Ne);
+  PG_REQUIRE(ws_bytes >= w.total, "encoder_bwd: workspace too small (%zu < %zu)", ws_bytes, w.total);
+  const int Hq = d->Hq, Dz = d->Dz, Vp = vpad(d), V = d->V, E = d->E;
+  float* scal = at<float>(ws, w.scalars);
+  const float inv_B = (dp && dp->kl_inv_batch > 0.0f) ? dp->kl_inv_batch : 1.0f / (float)B;
+  hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, st, scal, (int)SC_GS_KL, g_host, g_dev, -1, inv_B);
+  PG_CHECK_LAUNCH();
+  float* dq = at<float>(ws, w.b_dq);
+  T* dq_op = at<T>(ws, w.b_dq_op);
+  hipLaunchKernelGGL(reparam_bwd_kernel<T>, dim3(cdiv((long)B * Dz, 256)), dim3(256), 0, st, at<float>(ws, w.e_mulv),
+                     at<float>(ws, w.e_eps), dz, scal, B, Dz, dq, dq_op);
+  PG_CHECK_LAUNCH();
+  const T* hfin = at<T>(ws, w.e_hfin_op);
+  PG_TRY(launch_gemm_tn<T>(dq_op, 2 * Dz, hfin, Hq, Dz, Hq, B, grads + po.qmu_w, Hq, 1.0f, nullptr, st));
+  PG_TRY(launch_gemm_tn<T>(dq_op + Dz, 2 * Dz, hfin, Hq, Dz, Hq, B, grads + po.qlv_w, Hq, 1.0f, nullptr, st));
+  PG_TRY(colsum<T>(dq_op, B, Dz, 2 * Dz, grads + po.qmu_b, 1.0f, nullptr, st));
+  PG_TRY(colsum<T>(dq_op + Dz, B, Dz, 2 * Dz, grads + po.qlv_b, 1.0f, nullptr, st));
+  float* dhfin = at<float>(ws, w.b_dhfin);
+  {
+    GemmEpi<T> e;
+    e.C32 = dhfin; e.ldc = Hq;
+    PG_TRY(launch_gemm_nt<T>(dq_op, 2 * Dz, at<T>(shadow, so.wqT), 2 * Dz, B, Hq, 2 * Dz, e, st));
+  }
+  T* dGI = at<T>(ws, w.b_dGI);
+  T* dGH = at<T>(ws, w.b_dGH);
+  for (int t = se.T - 1; t >= 0; --t) {
+    GruBwdArgs<T> a;
+    a.H = Hq;
+    a.rows_out = sched_B(se, t);
+    a.rows_in = (t + 1 < se.T) ? sched_B(se, t + 1) : 0;
+    a.dGH_in = dGH + (long)se.off[t + 1 < se.T ? t + 1 : 0] * 3 * Hq;
+    a.WhhT = at<T>(shadow, so.enc_whhT);
+    a.dhz_in = at<float>(ws, w.b_dhz[(t + 1) & 1]);
+    a.inject = dhfin;
+    const long o = (long)se.off[t] * Hq;
+    a.sv_r = at<T>(ws, w.e_sv[0]) + o; a.sv_z = at<T>(ws, w.e_sv[1]) + o; a.sv_n = at<T>(ws, w.e_sv[2]) + o;
+    a.sv_hn = at<T>(ws, w.e_sv[3]) + o; a.sv_hprev = at<T>(ws, w.e_sv[4]) + o;
+    a.dGI = dGI + o * 3; a.dGH = dGH + o * 3;
+    a.dhz_out = at<float>(ws, w.b_dhz[t & 1]);
+    PG_TRY(launch_gru_bwd<T>(a, st));
+  }
+  PG_TRY(launch_gemm_tn<T>(dGH, 3 * Hq, at<T>(ws, w.e_sv[4]), Hq, 3 * Hq, Hq, (int)Ne, grads + po.enc_whh, Hq, 1.0f, nullptr, st));
+  PG_TRY(colsum<T>(dGH, Ne, 3 * Hq, 3 * Hq, grads + po.enc_bhh, 1.0f, nullptr, st));
+  PG_TRY(colsum<T>(dGI, Ne, 3 * Hq, 3 * Hq, grads + po.enc_bih, 1.0f, nullptr, st));
+  T* oh = at<T>(ws, w.b_onehot);
+  float* dT = at<float>(ws, w.b_dT);
+  hipLaunchKernelGGL(onehot_kernel<T>, dim3(ew_blocks(Ne * Vp)), dim3(256), 0, st, at<int>(ws, w.enc_tok), Ne, Vp, oh);
+  PG_CHECK_LAUNCH();
+  PG_CHECK_HIP(hipMemsetAsync(dT, 0, (size_t)Vp * 3 * Hq * 4, st));
+  PG_TRY(launch_gemm_tn<T>(oh, Vp, dGI, 3 * Hq, Vp, 3 * Hq, (int)Ne, dT, 3 * Hq, 1.0f, nullptr, st));
+  PG_TRY(small_gemm(dT, 3 * Hq, 1, params + po.enc_wih, E, 1, V, E, 3 * Hq, grads + po.x_emb, E, d->pad, st));
+  PG_TRY(small_gemm(dT, 1, 3 * Hq, params + po.x_emb, E, 1, 3 * Hq, E, V, grads + po.enc_wih, E, -1, st));
+  return PG_OK;
+}
+
+extern "C" int pg_encoder_bwd(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes,
+                              int B, int Tmax, const int32_t* h_lengths, const pg_dp* dp, const float* dz, float g_host,
+                              const float* g_dev, float* grads, void* stream) {
+  PG_TRY(check_dims(d, dtype));
+  PG_REQUIRE(params && shadow && ws && grads, "pg_encoder_bwd: NULL buffer");
+  return dtype == PG_BF16 ? encoder_bwd_t<bf16_t>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, h_lengths, dp, dz, g_host, g_dev,
+                                                  grads, (hipStream_t)stream)
+                          : encoder_bwd_t<float>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, h_lengths, dp, dz, g_host, g_dev,
+                                                 grads, (hipStream_t)stream);
+}
+
+// ===================================================================================================
+// optimiser
+// ===================================================================================================
+extern "C" int pg_clip_adam(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int step, float lr,
+                            float beta1, float beta2, float eps, float max_norm, float* scratch, float* gnorm, void* stream) {
+  PG_REQUIRE(n > 0 && params && grads && exp_avg && exp_avg_sq && scratch, "pg_clip_adam: NULL buffer");
+  PG_REQUIRE(step >= 1, "pg_clip_adam: step must be >= 1");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(PG_SUMSQ_BLOCKS), dim3(256), 0, st, grads, n, scratch);
+  PG_CHECK_LAUNCH();
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, scratch,
+                     (int)PG_SUMSQ_BLOCKS, max_norm, (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps, gnorm);
+  PG_CHECK_LAUNCH();
+  return PG_OK;
+}
