@@ -2,7 +2,7 @@
 #include "pg_gemm.h"
 #include "pg_mma.h"
 
-template <class Cfg>
+template <class Cfg, bool DROP>
 __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_nt_kernel(const typename Cfg::T* __restrict__ A, long lda,
                                                                  const typename Cfg::T* __restrict__ B, long ldb, int M,
                                                                  int N, int K, GemmEpi<typename Cfg::T> epi) {
@@ -12,12 +12,13 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_nt_kernel(const typename C
   const int bm = blockIdx.x / tiles_n, bn = blockIdx.x % tiles_n;
   const int m0 = bm * Cfg::BM, n0 = bn * Cfg::BN;
   f32x16 acc[Cfg::TM][Cfg::TN];
+{
+    const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
+    for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+      for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = zacc;
+  }
   RowSrc<T> as{A, lda, m0, M};
   RowSrc<T> bs{B, ldb, n0, N};
   mma_mainloop_nt<Cfg, Cfg::TN, Cfg::NGATE - 1>(acc, as, bs, K, smem);
@@ -26,25 +27,25 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_nt_kernel(const typename C
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   float alpha = epi.alpha;
   if (epi.alpha_dev) alpha *= *epi.alpha_dev;
-  const float inv_keep = epi.p_drop > 0.0f ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
+  const float inv_keep = DROP ? 1.0f / (1.0f - epi.p_drop) : 1.0f;
 #pragma unroll
   for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int m = m0 + Cfg::row_of(wm, tm, reg, lane);
-      if (m >= M) continue;
+      const bool mok = m < M;
       int rt = 0, rb = 0;
-      if (epi.p_drop > 0.0f) {
+      if (DROP && mok) {
         rt = epi.row_t[m];
         rb = epi.row_b[m] * epi.b_mul + epi.b_add;
       }
 #pragma unroll
       for (int tn = 0; tn < Cfg::TN; ++tn) {
         const int n = n0 + Cfg::col_in_group(wn, tn, lane & 31);
-        if (n >= N) continue;
         float v = acc[tm][tn][reg] * alpha;
+        if (!mok || n >= N) continue;
         if (epi.bias) v += epi.bias[n];
-        if (epi.p_drop > 0.0f) v *= dropout_scale(epi.seed, epi.layer, rt, rb, n, epi.p_drop, inv_keep);
+        if (DROP) v *= dropout_scale(epi.seed, epi.layer, rt, rb, n, epi.p_drop, inv_keep);
         const long o = (long)m * epi.ldc + n;
         if (epi.C32) {
           if (epi.accumulate) v += epi.C32[o];
@@ -67,12 +68,13 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_tn_kernel(const typename C
   const int r0 = blockIdx.y * rows_per_split;
   const int r1 = min(R, r0 + rows_per_split);
   f32x16 acc[Cfg::TM][Cfg::TN];
+{
+    const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
+    for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+      for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = zacc;
+  }
   mma_mainloop_tn<Cfg>(acc, A, lda, m0, M, B, ldb, n0, N, r0, r1, smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -82,12 +84,11 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_tn_kernel(const typename C
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int m = m0 + Cfg::row_of(wm, tm, reg, lane);
-      if (m >= M) continue;
 #pragma unroll
       for (int tn = 0; tn < Cfg::TN; ++tn) {
         const int n = n0 + Cfg::col_of(wn, tn, lane);
-        if (n >= N) continue;
-        atomicAdd(C + (long)m * ldc + n, acc[tm][tn][reg] * alpha);
+        const float v = acc[tm][tn][reg] * alpha;
+        if (m < M && n < N) atomicAdd(C + (long)m * ldc + n, v);
       }
     }
 }
@@ -104,11 +105,17 @@ int launch_gemm_nt(const T* A, long lda, const T* B, long ldb, int M, int N, int
   if (N <= 64) {
     using Cfg = TileCfg<T, 128, 64, 8, 4, 1>;
     dim3 grid(cdiv(M, Cfg::BM) * cdiv(N, Cfg::BN));
-    PG_LAUNCH_BIG_SMEM(gemm_nt_kernel<Cfg>, grid, dim3(Cfg::NTHREADS), Cfg::SMEM_BYTES, stream, A, lda, B, ldb, M, N, K, epi);
+    if (epi.p_drop > 0.0f)
+      PG_LAUNCH_BIG_SMEM((gemm_nt_kernel<Cfg, true>), grid, dim3(Cfg::NTHREADS), Cfg::SMEM_BYTES, stream, A, lda, B, ldb, M, N, K, epi);
+    else
+      PG_LAUNCH_BIG_SMEM((gemm_nt_kernel<Cfg, false>), grid, dim3(Cfg::NTHREADS), Cfg::SMEM_BYTES, stream, A, lda, B, ldb, M, N, K, epi);
   } else {
     using Cfg = TileCfg<T, 128, 128, 8, 2, 2>;
     dim3 grid(cdiv(M, Cfg::BM) * cdiv(N, Cfg::BN));
-    PG_LAUNCH_BIG_SMEM(gemm_nt_kernel<Cfg>, grid, dim3(Cfg::NTHREADS), Cfg::SMEM_BYTES, stream, A, lda, B, ldb, M, N, K, epi);
+    if (epi.p_drop > 0.0f)
+      PG_LAUNCH_BIG_SMEM((gemm_nt_kernel<Cfg, true>), grid, dim3(Cfg::NTHREADS), Cfg::SMEM_BYTES, stream, A, lda, B, ldb, M, N, K, epi);
+    else
+      PG_LAUNCH_BIG_SMEM((gemm_nt_kernel<Cfg, false>), grid, dim3(Cfg::NTHREADS), Cfg::SMEM_BYTES, stream, A, lda, B, ldb, M, N, K, epi);
   }
   PG_CHECK_LAUNCH();
   return PG_OK;

@@ -19,12 +19,13 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gru_fwd_kernel(GruFwdArgs<typen
   const int H = a.H;
   const int j0 = blockIdx.x * BH, m0 = blockIdx.y * Cfg::BM;
   f32x16 acc[Cfg::TM][NACC];
+{
+    const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
+    for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
-    for (int j = 0; j < NACC; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+      for (int j = 0; j < NACC; ++j) acc[i][j] = zacc;
+  }
   if (a.hprev_op) {
     RowSrc<T> as{a.hprev_op, H, m0, a.rows};
     GateRowSrc<T> bs{a.Whh, H, H, j0, BH};
@@ -100,12 +101,13 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gru_bwd_kernel(GruBwdArgs<typen
   const int H = a.H;
   const int j0 = blockIdx.x * Cfg::BN, m0 = blockIdx.y * Cfg::BM;
   f32x16 acc[Cfg::TM][Cfg::TN];
+{
+    const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
+    for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+      for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = zacc;
+  }
   if (a.rows_in > 0 && m0 < a.rows_in) {
     RowSrc<T> as{a.dGH_in, 3L * H, m0, a.rows_in};
     RowSrc<T> bs{a.WhhT, 3L * H, j0, H};

@@ -27,14 +27,14 @@ template <> struct MmaOp<float> {
   }
 };
 
-// Row-pointer functors: return the address of tile row `r` (K-contiguous) or nullptr for an out-of-range row.
+// Row functors: element offset (from .base) of tile row `r` (K-contiguous), or -1 for an out-of-range row.
 template <typename T> struct RowSrc {
   const T* base;
   long ld;
   int row0, nrows;
-  __device__ __forceinline__ const T* operator()(int r) const {
+  __device__ __forceinline__ long operator()(int r) const {   // element offset of tile row r, -1 if out of range
     int g = row0 + r;
-    return g < nrows ? base + (long)g * ld : nullptr;
+    return g < nrows ? (long)g * ld : -1L;
   }
 };
 // Weight rows of a GRU: tile row n = gate*BH + jj maps to weight row gate*H + j0 + jj.
@@ -42,9 +42,9 @@ template <typename T> struct GateRowSrc {
   const T* base;
   long ld;
   int H, j0, BH;
-  __device__ __forceinline__ const T* operator()(int n) const {
+  __device__ __forceinline__ long operator()(int n) const {
     int g = n / BH, j = j0 + (n - g * BH);
-    return j < H ? base + (long)(g * H + j) * ld : nullptr;
+    return j < H ? (long)(g * H + j) * ld : -1L;
   }
 };
 
@@ -85,16 +85,17 @@ __device__ __forceinline__ void mma_mainloop_nt(f32x16 (&acc)[Cfg::TM][NACC], co
   constexpr int NT = Cfg::NTHREADS, BKC = Cfg::BKC, EPC = Cfg::EPC, ROWB = Cfg::ROWB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
-  const T* pa[Cfg::A_IT];
-  const T* pb[Cfg::B_IT];
+  const T* __restrict__ abase = asrc.base;
+  const T* __restrict__ bbase = bsrc.base;
+  long pa[Cfg::A_IT], pb[Cfg::B_IT];
   int oa[Cfg::A_IT], ob[Cfg::B_IT];
 #pragma unroll
   for (int i = 0; i < Cfg::A_IT; ++i) {
     int id = tid + i * NT;
     int row = id / BKC, c = id % BKC;
     bool ok = id < Cfg::BM * BKC;
-    pa[i] = ok ? asrc(row) : nullptr;
-    if (pa[i]) pa[i] += c * EPC;
+    long o = ok ? asrc(row) : -1L;
+    pa[i] = o >= 0 ? o + c * EPC : -1L;
     oa[i] = ok ? row * ROWB + c * 16 : -1;
   }
 #pragma unroll
@@ -102,27 +103,30 @@ __device__ __forceinline__ void mma_mainloop_nt(f32x16 (&acc)[Cfg::TM][NACC], co
     int id = tid + i * NT;
     int row = id / BKC, c = id % BKC;
     bool ok = id < Cfg::BN * BKC;
-    pb[i] = ok ? bsrc(row) : nullptr;
-    if (pb[i]) pb[i] += c * EPC;
+    long o = ok ? bsrc(row) : -1L;
+    pb[i] = o >= 0 ? o + c * EPC : -1L;
     ob[i] = ok ? row * ROWB + c * 16 : -1;
   }
   uint4 ra[Cfg::A_IT], rb[Cfg::B_IT];
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
   const int nk = (K + Cfg::BK - 1) / Cfg::BK;
-  auto gload = [&](int kt) {
+  // k0 >= K on the (dummy) prefetch of the last iteration: every chunk is then predicated off
+  auto gload = [&](int kt) __attribute__((always_inline)) {
     const int k0 = kt * Cfg::BK;
 #pragma unroll
     for (int i = 0; i < Cfg::A_IT; ++i) {
       int c = (tid + i * NT) % BKC;
-      ra[i] = (pa[i] && k0 + c * EPC < K) ? *reinterpret_cast<const uint4*>(pa[i] + k0) : zero4;
+      ra[i] = zero4;
+      if (pa[i] >= 0 && k0 + c * EPC < K) ra[i] = *reinterpret_cast<const uint4*>(abase + pa[i] + k0);
     }
 #pragma unroll
     for (int i = 0; i < Cfg::B_IT; ++i) {
       int c = (tid + i * NT) % BKC;
-      rb[i] = (pb[i] && k0 + c * EPC < K) ? *reinterpret_cast<const uint4*>(pb[i] + k0) : zero4;
+      rb[i] = zero4;
+      if (pb[i] >= 0 && k0 + c * EPC < K) rb[i] = *reinterpret_cast<const uint4*>(bbase + pb[i] + k0);
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf) __attribute__((always_inline)) {
     char* sa = smem + buf * Cfg::STAGE_BYTES;
     char* sb = sa + Cfg::A_BYTES;
 #pragma unroll
@@ -133,7 +137,7 @@ __device__ __forceinline__ void mma_mainloop_nt(f32x16 (&acc)[Cfg::TM][NACC], co
       if (ob[i] >= 0) *reinterpret_cast<uint4*>(sb + ob[i]) = rb[i];
   };
   const int lr = lane & 31, lh = lane >> 5;
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf) __attribute__((always_inline)) {
     const char* sa = smem + buf * Cfg::STAGE_BYTES;
     const char* sb = sa + Cfg::A_BYTES;
 #pragma unroll
@@ -157,15 +161,13 @@ __device__ __forceinline__ void mma_mainloop_nt(f32x16 (&acc)[Cfg::TM][NACC], co
         }
     }
   };
-  if (nk > 0) {
-    gload(0);
-    sstore(0);
-  }
+  gload(0);
+  sstore(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) gload(kt + 1);
+    gload(kt + 1);   // the last one is fully predicated off (zeros into the idle buffer)
     compute(kt & 1);
-    if (kt + 1 < nk) sstore((kt + 1) & 1);
+    sstore((kt + 1) & 1);
     __syncthreads();
   }
 }
@@ -227,8 +229,8 @@ template <> struct TnFrag<float> {
 
 // acc += A[r0:r1, m0:m0+BM]^T B[r0:r1, n0:n0+BN].  Columns >= Mtot / Ntot and rows >= r1 read as zero.
 template <class Cfg>
-__device__ __forceinline__ void mma_mainloop_tn(f32x16 (&acc)[Cfg::TM][Cfg::TN], const typename Cfg::T* A, long lda,
-                                                int m0, int Mtot, const typename Cfg::T* B, long ldb, int n0,
+__device__ __forceinline__ void mma_mainloop_tn(f32x16 (&acc)[Cfg::TM][Cfg::TN], const typename Cfg::T* __restrict__ A, long lda,
+                                                int m0, int Mtot, const typename Cfg::T* __restrict__ B, long ldb, int n0,
                                                 int Ntot, int r0, int r1, char* smem) {
   using T = typename Cfg::T;
   constexpr int NT = Cfg::NTHREADS, EPC = Cfg::EPC;
@@ -237,22 +239,24 @@ __device__ __forceinline__ void mma_mainloop_tn(f32x16 (&acc)[Cfg::TM][Cfg::TN],
   uint4 ra[Cfg::A_IT], rb[Cfg::B_IT];
   const uint4 zero4 = make_uint4(0, 0, 0, 0);
   const int nk = (r1 - r0 + Cfg::BKR - 1) / Cfg::BKR;
-  auto gload = [&](int kt) {
+  auto gload = [&](int kt) __attribute__((always_inline)) {
     const int rr = r0 + kt * Cfg::BKR;
 #pragma unroll
     for (int i = 0; i < Cfg::A_IT; ++i) {
       int id = tid + i * NT, kr = id / Cfg::ACH, c = id % Cfg::ACH;
       bool ok = id < Cfg::BKR * Cfg::ACH && rr + kr < r1 && m0 + c * EPC < Mtot;
-      ra[i] = ok ? *reinterpret_cast<const uint4*>(A + (long)(rr + kr) * lda + m0 + c * EPC) : zero4;
+      ra[i] = zero4;
+      if (ok) ra[i] = *reinterpret_cast<const uint4*>(A + (long)(rr + kr) * lda + m0 + c * EPC);
     }
 #pragma unroll
     for (int i = 0; i < Cfg::B_IT; ++i) {
       int id = tid + i * NT, kr = id / Cfg::BCH, c = id % Cfg::BCH;
       bool ok = id < Cfg::BKR * Cfg::BCH && rr + kr < r1 && n0 + c * EPC < Ntot;
-      rb[i] = ok ? *reinterpret_cast<const uint4*>(B + (long)(rr + kr) * ldb + n0 + c * EPC) : zero4;
+      rb[i] = zero4;
+      if (ok) rb[i] = *reinterpret_cast<const uint4*>(B + (long)(rr + kr) * ldb + n0 + c * EPC);
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf) __attribute__((always_inline)) {
     char* sa = smem + buf * Cfg::STAGE_BYTES;
     char* sb = sa + Cfg::A_BYTES;
 #pragma unroll
@@ -266,7 +270,7 @@ __device__ __forceinline__ void mma_mainloop_tn(f32x16 (&acc)[Cfg::TM][Cfg::TN],
       if (id < Cfg::BKR * Cfg::BCH) *reinterpret_cast<uint4*>(sb + kr * Cfg::ROWBB + c * 16) = rb[i];
     }
   };
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf) __attribute__((always_inline)) {
     const char* sa = smem + buf * Cfg::STAGE_BYTES;
     const char* sb = sa + Cfg::A_BYTES;
 #pragma unroll
@@ -284,15 +288,13 @@ __device__ __forceinline__ void mma_mainloop_tn(f32x16 (&acc)[Cfg::TM][Cfg::TN],
         for (int tn = 0; tn < Cfg::TN; ++tn) TnFrag<T>::mma(acc[tm][tn], fa[tm], fb[tn]);
     }
   };
-  if (nk > 0) {
-    gload(0);
-    sstore(0);
-  }
+  gload(0);
+  sstore(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) gload(kt + 1);
+    gload(kt + 1);   // the last one is fully predicated off (zeros into the idle buffer)
     compute(kt & 1);
-    if (kt + 1 < nk) sstore((kt + 1) & 1);
+    sstore((kt + 1) & 1);
     __syncthreads();
   }
 }

@@ -41,12 +41,13 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void sample_head_kernel(const typena
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int m0 = blockIdx.x * Cfg::BM;
   f32x16 acc[Cfg::TM][Cfg::TN];
+{
+    const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < Cfg::TM; ++i)
+    for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
-    for (int j = 0; j < Cfg::TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+      for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = zacc;
+  }
   RowSrc<T> as{htop, H, m0, n};
   RowSrc<T> bs{fcw, H, 0, Cfg::BN};
   mma_mainloop_nt<Cfg, Cfg::TN, 0>(acc, as, bs, H, smem);

@@ -226,6 +226,43 @@ class _Engine:
                                     ctypes.byref(dp) if dp is not None else None, _lib.ptr(dz), ctypes.c_float(g_host),
                                     _lib.ptr(g_dev), _lib.ptr(grads), _lib.stream_ptr()), "pg_encoder_bwd")
 
+    # ---- fused training step (no autograd): the data-parallel hot path ------------------------------------
+    def decoder_param_start(self):
+        """Index in the flat buffers where the decoder-only parameters (decoder_lat .. decoder_fc) start."""
+        ps = self.params()
+        return sum(p.numel() for p in ps[:9])
+
+    def train_step(self, batch, kl_weight, grads, eps=None, dp=None, p_drop=0.0, seed=0, comm=None):
+        """forward + hand-written BPTT of  kl_weight * kl + recon  into the flat ``grads`` buffer (zeroed here).
+        ``comm`` (optional polygon_amd.parallel.GradComm) all-reduces the decoder bucket while the encoder BPTT
+        runs, then the encoder bucket.  Returns device scalars (kl, recon)."""
+        self.ensure_shadow()
+        dev = self.flat.device
+        B = len(batch)
+        L = _lib.lib()
+        L.pg_train_workspace_bytes.restype = ctypes.c_size_t
+        need = L.pg_train_workspace_bytes(ctypes.byref(self.dims), self.dtype_code(), int(B), ctypes.c_long(batch.n_tokens))
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < need or ws.device != dev:
+            ws = self._ws = torch.empty(int(need * 1.25), dtype=torch.uint8, device=dev)
+        sm = getattr(self, "_small", None)
+        if sm is None or sm[0].shape[0] < B or sm[0].device != dev:
+            sm = self._small = (torch.empty(max(B, 64), self.dims.Dz, device=dev), torch.empty(max(B, 64), self.dims.Dz, device=dev),
+                                torch.empty(2, device=dev))
+        z, dz, scal = sm
+        if eps is None:
+            eps = torch.randn(B, self.dims.Dz, device=dev)
+        grads.zero_()
+        self.encoder_fwd(ws, batch, eps, dp, 1, z, None, None, scal[0:1])
+        self.decoder_fwd(ws, batch, z, dp, p_drop, seed, 0, 1, scal[1:2])
+        self.decoder_bwd(ws, batch, dp, p_drop, seed, 0, 1.0, None, grads, dz)
+        if comm is not None:
+            comm.start_decoder_bucket(grads, self.decoder_param_start())
+        self.encoder_bwd(ws, batch, dp, dz, float(kl_weight), None, grads)
+        if comm is not None:
+            comm.finish(grads, self.decoder_param_start())
+        return scal[0], scal[1]
+
     def grad_views(self, flat_grad):
         out, off = [], 0
         for p in self.params():

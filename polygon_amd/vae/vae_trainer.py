@@ -1,0 +1,235 @@
+"""Trainer of the SMILES VAE: the reference's interface (polygon/vae/vae_trainer.py:16-292) over the fused HIP step.
+
+``VAETrainer(model, **kwargs).fit(train, val, n_epoch, batch_size, save_frequency)`` keeps the reference's defaults,
+kwargs-override convention, CSV log, checkpoint cadence and quirks (``batch_size`` is ignored in favour of ``n_batch``;
+a fresh Adam and fresh annealers per ``fit``).  The per-batch body -- forward, ``kl_w*kl + recon``, backward,
+``clip_grad_norm_(50)``, ``Adam.step`` (vae_trainer.py:121-138) -- runs as five C-ABI calls with no autograd graph and,
+under torch.distributed, an overlapped RCCL gradient all-reduce (polygon_amd/parallel.py).
+"""
+import ctypes
+import logging
+import os
+import time
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from polygon_amd import _lib
+from polygon_amd.parallel import GradComm, global_batch_stats, world_info
+from polygon_amd.utils.moses_utils import CircularBuffer, set_torch_seed_to_all_gens
+from polygon_amd.utils.utils import save_model
+from polygon_amd.vae.vae_misc import CosineAnnealingLRWithRestart, KLAnnealer
+from polygon_amd.vae.vae_model import TokenBatch, _Dp
+
+
+class FusedClipAdam(torch.optim.Optimizer):
+    """torch.optim.Adam(defaults) + clip_grad_norm_ over the model's flat buffers in two kernels (pg_clip_adam).
+    A regular torch Optimizer as far as schedulers are concerned (param_groups[0]['lr'])."""
+
+    def __init__(self, model, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, clip_grad=50.0):
+        params = [p for p in model.vae.parameters() if p.requires_grad]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.model = model
+        self.clip_grad = clip_grad
+        eng = model._engine
+        flat = eng.ensure_flat()
+        self.flat_grad = torch.zeros_like(flat)
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.scratch = torch.zeros(4096, device=flat.device)
+        self.gnorm = torch.zeros((), device=flat.device)
+        self.n_steps = 0
+        # frozen parameters (freeze_embeddings): their gradient range is zeroed before the update
+        self.frozen = []
+        off = 0
+        for p in model.vae.parameters():
+            if not p.requires_grad:
+                self.frozen.append((off, off + p.numel()))
+            off += p.numel()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        eng = self.model._engine
+        flat = eng.ensure_flat()
+        if flat.data_ptr() != self.exp_avg.data_ptr() and flat.shape != self.exp_avg.shape:
+            raise RuntimeError("model parameters changed shape under the optimiser")
+        for a, b in self.frozen:
+            self.flat_grad[a:b].zero_()
+        g = self.param_groups[0]
+        self.n_steps += 1
+        _lib.check(_lib.lib().pg_clip_adam(ctypes.c_long(flat.numel()), _lib.ptr(flat), _lib.ptr(self.flat_grad),
+                                           _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), self.n_steps,
+                                           ctypes.c_float(g['lr']), ctypes.c_float(g['betas'][0]),
+                                           ctypes.c_float(g['betas'][1]), ctypes.c_float(g['eps']),
+                                           ctypes.c_float(self.clip_grad if self.clip_grad else 0.0), _lib.ptr(self.scratch),
+                                           _lib.ptr(self.gnorm), _lib.stream_ptr()), "pg_clip_adam")
+        eng.invalidate()
+
+
+class VAETrainer:
+    def __init__(self, model, **kwargs):
+        self.model = model
+        # defaults (vae_trainer.py:21-39)
+        self.log_file = None
+        self.model_save = "model_{}.pt".format(int(time.time()))
+        self.save_frequency = 1
+        self.n_workers = 0
+        self.n_batch = 512
+        self.n_epoch = 10
+        self.n_last = 1000
+        self.clip_grad = 50
+        self.lr_start = 0.0003
+        self.kl_w_start = 0
+        self.kl_start = 1
+        self.kl_w_end = 1
+        self.lr_n_period = 10
+        self.lr_n_restarts = 6
+        self.lr_n_mult = 1
+        self.lr_end = 0.0003
+        self.__dict__.update(kwargs)
+        self.device = self.model.device
+
+    def _n_epoch(self):
+        if self.n_epoch:
+            return self.n_epoch
+        return sum(self.lr_n_period * (self.lr_n_mult ** i) for i in range(self.lr_n_restarts))
+
+    def _save_model(self, output_path=None):
+        save_model(self.model, self.model_save if output_path is None else output_path)
+
+    def get_dataloader(self, data, batch_size=None, collate_fn=None, shuffle=True):
+        """vae_trainer.py:78-97.  ``batch_size`` is accepted and ignored exactly as the reference does (``n_batch`` is
+        used).  Under data parallelism the loader yields GLOBAL batches of n_batch * world strings, identically
+        shuffled on every rank (shared generator seed); ``_train_epoch`` takes this rank's shard."""
+        if collate_fn is None:
+            collate_fn = self.model.get_collate_fn()
+        rank, world = world_info()
+        gen = None
+        if world > 1 and shuffle:
+            seed = torch.tensor([torch.initial_seed() % (2 ** 31)], dtype=torch.int64)
+            if torch.distributed.get_backend() == "nccl":
+                seed = seed.cuda()
+            torch.distributed.broadcast(seed, 0)
+            gen = torch.Generator().manual_seed(int(seed.item()))
+        return DataLoader(data, batch_size=self.n_batch * world, shuffle=shuffle, num_workers=self.n_workers,
+                          collate_fn=collate_fn, generator=gen,
+                          worker_init_fn=set_torch_seed_to_all_gens if self.n_workers > 0 else None)
+
+    def get_optim_params(self):
+        return (p for p in self.model.vae.parameters() if p.requires_grad)
+
+    # ---- one epoch (vae_trainer.py:102-189) -----------------------------------------------------------------
+    def _train_epoch(self, epoch, data_loader, kl_weight, optimizer=None, label="Training"):
+        t_epoch = time.process_time()
+        model = self.model
+        if optimizer is None:
+            model.eval()
+        else:
+            model.train()
+        n_batches = len(data_loader)
+        kl_buf, rec_buf, loss_buf = CircularBuffer(n_batches), CircularBuffer(n_batches), CircularBuffer(n_batches)
+        fused = isinstance(optimizer, FusedClipAdam)
+        rank, world = world_info()
+        comm = GradComm() if (world > 1 and fused) else None
+        eng = model._engine
+        debug = logging.getLogger().isEnabledFor(logging.DEBUG)
+        pending = []          # device scalars read back once per epoch unless per-batch debug logging is on
+        lr = 0.
+        for i, batch in enumerate(data_loader):
+            t_batch = time.process_time()
+            dp = None
+            if world > 1:
+                inv_b, cnt = global_batch_stats(batch.lengths)
+                dp = _Dp(kl_inv_batch=inv_b, ce_count=cnt, b_mul=world, b_add=rank)
+                batch = batch.shard(rank, world)
+            if fused:
+                p_drop = float(model.d_dropout) if model.d_n_layers > 1 else 0.0
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_drop > 0 else 0
+                eng.ensure_shadow()
+                b = batch if isinstance(batch, TokenBatch) else None
+                if b is None:
+                    from polygon_amd.vae.vae_model import _as_batch
+                    b = _as_batch(batch, model.pad, eng.flat.device)
+                kl_loss, recon_loss = eng.train_step(b, kl_weight, optimizer.flat_grad, dp=dp, p_drop=p_drop, seed=seed,
+                                                     comm=comm)
+                loss = kl_weight * kl_loss + recon_loss
+                optimizer.step()
+            else:
+                kl_loss, recon_loss = model(batch)
+                loss = kl_weight * kl_loss + recon_loss
+                if optimizer is not None:
+                    optimizer.zero_grad()
+                    loss.backward()
+                    torch.nn.utils.clip_grad_norm_(self.get_optim_params(), self.clip_grad)
+                    optimizer.step()
+            lr = optimizer.param_groups[0]['lr'] if optimizer is not None else 0.
+            vals = torch.stack([kl_loss.detach().reshape(()), recon_loss.detach().reshape(()), loss.detach().reshape(())])
+            if debug:
+                k, r, l = vals.tolist()
+                kl_buf.add(k); rec_buf.add(r); loss_buf.add(l)
+                logging.debug(' '.join([label, f'Batch {str(i).zfill(len(str(n_batches)))}/{n_batches}',
+                                        f'Time={time.process_time() - t_batch:.2f}', f'loss={l:.5f}', f'(kl={k:.5f}',
+                                        f'recon={r:.5f})', f'klw={kl_weight:.5f}', f'lr={lr:.5f}']))
+            else:
+                pending.append(vals)
+        if pending:
+            for k, r, l in torch.stack(pending).tolist():
+                kl_buf.add(k); rec_buf.add(r); loss_buf.add(l)
+        kl_v, rec_v, loss_v = kl_buf.mean(), rec_buf.mean(), loss_buf.mean()
+        logging.info(' '.join([label, f'Time={time.process_time() - t_epoch:.2f}', f'loss={loss_v:.5f}', f'(kl={kl_v:.5f}',
+                               f'recon={rec_v:.5f})', f'klw={kl_weight:.5f}', f'lr={lr:.5f}']))
+        return {'epoch': epoch, 'kl_weight': kl_weight, 'lr': lr, 'kl_loss': kl_v, 'recon_loss': rec_v, 'loss': loss_v,
+                'mode': 'Eval' if optimizer is None else 'Train'}
+
+    def _log_epoch(self, postfix, header=False):
+        columns = ['epoch', 'kl_weight', 'lr', 'kl_loss', 'recon_loss', 'loss', 'mode']
+        if self.log_file is None:
+            return
+        with open(self.log_file, "a+") as handle:
+            handle.write(",".join(columns if header else [str(postfix[c]) for c in columns]) + "\n")
+
+    def _make_optimizer(self):
+        """Adam(lr_start) as vae_trainer.py:217-218; fused when the model lives on the GPU (always, in practice)."""
+        return FusedClipAdam(self.model, lr=self.lr_start, clip_grad=self.clip_grad)
+
+    def _train(self, train_loader, val_loader=None, n_epoch=None, save_frequency=None):
+        if n_epoch is None:
+            n_epoch = self._n_epoch()
+        if save_frequency is None:
+            save_frequency = self.save_frequency
+        optimizer = self._make_optimizer()
+        kl_annealer = KLAnnealer(n_epoch, kl_start=self.kl_start, kl_w_end=self.kl_w_end, kl_w_start=self.kl_w_start)
+        lr_annealer = CosineAnnealingLRWithRestart(optimizer, lr_n_period=self.lr_n_period, lr_n_restarts=self.lr_n_restarts,
+                                                   lr_n_mult=self.lr_n_mult, lr_end=self.lr_end)
+        self.model.zero_grad()
+        rank, _ = world_info()
+        width = len(str(n_epoch))
+        for epoch in range(n_epoch):
+            kl_weight = kl_annealer(epoch)
+            postfix = self._train_epoch(epoch, train_loader, kl_weight, optimizer,
+                                        label='Training   (epoch #{})'.format(str(epoch).zfill(width)))
+            if rank == 0:
+                self._log_epoch(postfix)
+            if val_loader is not None:
+                postfix = self._train_epoch(epoch, val_loader, kl_weight,
+                                            label='Validation (epoch #{})'.format(str(epoch).zfill(width)))
+                if rank == 0:
+                    self._log_epoch(postfix)
+            if (self.model_save is not None) and (epoch % save_frequency == 0) and rank == 0:
+                save_model(self.model, output_path='{path}_{epoch:03d}.pt'.format(
+                    path=os.path.splitext(self.model_save)[0], epoch=epoch))
+            lr_annealer.step()
+
+    def fit(self, train_data, val_data=None, n_epoch=None, batch_size=None, save_frequency=None):
+        rank, _ = world_info()
+        if self.log_file is not None and rank == 0:
+            lines = ["Training Parameters:", "\n".join("{}: {}".format(k, v) for k, v in self.__dict__.items()),
+                     "----------------------"]
+            with open(self.log_file, "w") as handle:
+                handle.write("\n".join(lines) + "\n")
+        train_loader = self.get_dataloader(train_data, batch_size=batch_size, shuffle=True)
+        val_loader = None if val_data is None else self.get_dataloader(val_data, batch_size=batch_size, shuffle=False)
+        self._train(train_loader, val_loader, n_epoch=n_epoch, save_frequency=save_frequency)
+        if self.model_save is not None and rank == 0:
+            save_model(self.model, output_path=self.model_save)
