@@ -118,6 +118,11 @@ PG_API int pg_gemm_nt(int dtype, const void* A, long lda, const void* B, long ld
 PG_API int pg_gemm_tn(int dtype, const void* A, long lda, const void* B, long ldb, int M, int N, int R, float* C, long ldc,
                       float alpha, void* stream);
 
+/* pg_bench_gru: launches one recurrent step kernel (which = 0 forward cell, 1 backward cell) `repeat` times on
+ * scratch operands carved from ws (>= 64*rows*H bytes + 16*H*H bytes): used by bench.py to time the dominant kernel
+ * with HIP events, and by the kernel-tuning scripts under tools/. */
+PG_API int pg_bench_gru(int dtype, int which, int rows, int H, void* ws, size_t ws_bytes, int repeat, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

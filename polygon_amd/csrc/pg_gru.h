@@ -30,6 +30,7 @@ template <typename T> struct GruFwdArgs {
   float p_drop = 0.0f;
   unsigned long long seed = 0;
   int layer = 0, t = 0, b_mul = 1, b_add = 0;
+  int dbg = 0;  // timing experiments only: 1 = skip main loop, 2 = skip epilogue, 4 = skip stores
 };
 
 template <typename T> struct GruBwdArgs {
@@ -46,6 +47,7 @@ template <typename T> struct GruBwdArgs {
   int final_step = 0;            // 1: only dh0 (+)= acc + dhz_in for rows_out rows
   float* dh0 = nullptr;
   int dh0_accumulate = 0;
+  int dbg = 0;
 };
 
 template <typename T> int launch_gru_fwd(const GruFwdArgs<T>& a, hipStream_t stream);

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gru_fwd_kernel(GruFwdArgs<typen
 #pragma unroll
       for (int j = 0; j < NACC; ++j) acc[i][j] = zacc;
   }
-  if (a.hprev_op) {
+  if (a.hprev_op && !(a.dbg & 1)) {
     RowSrc<T> as{a.hprev_op, H, m0, a.rows};
     GateRowSrc<T> bs{a.Whh, H, H, j0, BH};
     mma_mainloop_nt<Cfg, NACC, 2>(acc, as, bs, H, smem);
@@ -39,54 +39,69 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gru_fwd_kernel(GruFwdArgs<typen
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const float inv_keep = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+  if (a.dbg & 2) { if (acc[0][0][0] == 123.456f) a.h32[0] = 1.0f; return; }
+  // Epilogue in two phases per 16-row group: FIRST gather every input into registers (independent loads, all in flight
+  // together), THEN compute and store.  Interleaving loads and stores per element would serialise one memory round
+  // trip per element, because the output pointers may alias the inputs as far as the compiler knows.
 #pragma unroll
   for (int tu = 0; tu < TU; ++tu) {
     const int j = j0 + Cfg::col_in_group(wn, tu, lane & 31);
-    if (j >= H) continue;
-    const float bhn = a.bhn[j];
+    const bool jok = j < H;
+    const float bhn = jok ? a.bhn[j] : 0.0f;
     float bg_r = 0.f, bg_z = 0.f, bg_n = 0.f;
-    if (MODE == PG_GI_FUSED) {
+    if (MODE == PG_GI_FUSED && jok) {
       bg_r = a.bias_gi[j]; bg_z = a.bias_gi[H + j]; bg_n = a.bias_gi[2 * H + j];
     }
 #pragma unroll
-    for (int tm = 0; tm < Cfg::TM; ++tm)
+    for (int tm = 0; tm < Cfg::TM; ++tm) {
+      float gr[16], gz[16], gn[16], hp[16];
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int b = m0 + Cfg::row_of(wm, tm, reg, lane);
-        if (b >= a.rows) continue;
-        float gr, gz, gn;
-        if (MODE == PG_GI_ARRAY) {
-          const float* g = a.gi + (long)b * 3 * H;
-          gr = g[j]; gz = g[H + j]; gn = g[2 * H + j];
-        } else if (MODE == PG_GI_TABLE) {
-          const float* g = a.table + (long)a.tok[b] * 3 * H;
-          gr = g[j]; gz = g[H + j]; gn = g[2 * H + j];
-          if (a.zproj) {
-            const float* zp = a.zproj + (long)b * 3 * H;
-            gr += zp[j]; gz += zp[H + j]; gn += zp[2 * H + j];
+        const bool ok = jok && b < a.rows;
+        gr[reg] = bg_r; gz[reg] = bg_z; gn[reg] = bg_n; hp[reg] = 0.0f;
+        if (ok) {
+          if (MODE == PG_GI_ARRAY) {
+            const float* g = a.gi + (long)b * 3 * H;
+            gr[reg] = g[j]; gz[reg] = g[H + j]; gn[reg] = g[2 * H + j];
+          } else if (MODE == PG_GI_TABLE) {
+            const float* g = a.table + (long)a.tok[b] * 3 * H;
+            gr[reg] = g[j]; gz[reg] = g[H + j]; gn[reg] = g[2 * H + j];
+            if (a.zproj) {
+              const float* zp = a.zproj + (long)b * 3 * H;
+              gr[reg] += zp[j]; gz[reg] += zp[H + j]; gn[reg] += zp[2 * H + j];
+            }
           }
-        } else {
-          gr = bg_r; gz = bg_z; gn = bg_n + acc[tm][3 * TU + tu][reg];
+          if (a.hprev32) hp[reg] = a.hprev32[(long)b * H + j];
         }
-        const float r = sigmoidf_(gr + acc[tm][tu][reg]);
-        const float z = sigmoidf_(gz + acc[tm][TU + tu][reg]);
-        const float hn = acc[tm][2 * TU + tu][reg] + bhn;
-        const float n = tanhf_(gn + r * hn);
-        const long o = (long)b * H + j;
-        const float hp = a.hprev32 ? a.hprev32[o] : 0.0f;
-        const float h = (1.0f - z) * n + z * hp;
-        a.h32[o] = h;
-        a.h_op[o] = from_f32<T>(h);
-        if (a.sv_r) {
-          a.sv_r[o] = from_f32<T>(r);
-          a.sv_z[o] = from_f32<T>(z);
-          a.sv_n[o] = from_f32<T>(n);
-          a.sv_hn[o] = from_f32<T>(hn);
-          a.sv_hprev[o] = from_f32<T>(hp);
-        }
-        if (a.h_drop)
-          a.h_drop[o] = from_f32<T>(h * dropout_scale(a.seed, a.layer, a.t, b * a.b_mul + a.b_add, j, a.p_drop, inv_keep));
       }
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int b = m0 + Cfg::row_of(wm, tm, reg, lane);
+        const bool ok = jok && b < a.rows;
+        float gnn = gn[reg];
+        if (MODE == PG_GI_FUSED) gnn += acc[tm][3 * TU + tu][reg];
+        const float r = sigmoidf_(gr[reg] + acc[tm][tu][reg]);
+        const float z = sigmoidf_(gz[reg] + acc[tm][TU + tu][reg]);
+        const float hn = acc[tm][2 * TU + tu][reg] + bhn;
+        const float n = tanhf_(gnn + r * hn);
+        const float h = (1.0f - z) * n + z * hp[reg];
+        if (ok) {
+          const long o = (long)b * H + j;
+          a.h32[o] = h;
+          a.h_op[o] = from_f32<T>(h);
+          if (a.sv_r) {
+            a.sv_r[o] = from_f32<T>(r);
+            a.sv_z[o] = from_f32<T>(z);
+            a.sv_n[o] = from_f32<T>(n);
+            a.sv_hn[o] = from_f32<T>(hn);
+            a.sv_hprev[o] = from_f32<T>(hp[reg]);
+          }
+          if (a.h_drop)
+            a.h_drop[o] = from_f32<T>(h * dropout_scale(a.seed, a.layer, a.t, b * a.b_mul + a.b_add, j, a.p_drop, inv_keep));
+        }
+      }
+    }
   }
 }
 
@@ -108,47 +123,330 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gru_bwd_kernel(GruBwdArgs<typen
 #pragma unroll
       for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = zacc;
   }
-  if (a.rows_in > 0 && m0 < a.rows_in) {
+  if (a.rows_in > 0 && m0 < a.rows_in && !(a.dbg & 1)) {
     RowSrc<T> as{a.dGH_in, 3L * H, m0, a.rows_in};
     RowSrc<T> bs{a.WhhT, 3L * H, j0, H};
     mma_mainloop_nt<Cfg, Cfg::TN, 0>(acc, as, bs, 3 * H, smem);
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  if (a.dbg & 2) { if (acc[0][0][0] == 123.456f) a.dhz_out[0] = 1.0f; return; }
 #pragma unroll
   for (int tn = 0; tn < Cfg::TN; ++tn) {
     const int j = j0 + Cfg::col_in_group(wn, tn, lane & 31);
-    if (j >= H) continue;
+    const bool jok = j < H;
 #pragma unroll
     for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int b = m0 + Cfg::row_of(wm, tm, reg, lane);
-        if (b >= a.rows_out) continue;
-        const long o = (long)b * H + j;
-        float dh = 0.0f;
-        if (b < a.rows_in) dh = acc[tm][tn][reg] + a.dhz_in[o];
-        else if (a.inject) dh = a.inject[o];
-        if (a.final_step) {
-          a.dh0[o] = a.dh0_accumulate ? a.dh0[o] + dh : dh;
-          continue;
+      for (int half = 0; half < 2; ++half) {   // 8 rows at a time: gather all inputs first, then compute + store
+        float dh[8], r[8], z[8], n[8], hn[8], hp[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int reg = half * 8 + q;
+          const int b = m0 + Cfg::row_of(wm, tm, reg, lane);
+          const bool ok = jok && b < a.rows_out;
+          const long o = (long)b * H + j;
+          float d = 0.0f;
+          r[q] = z[q] = n[q] = hn[q] = hp[q] = 0.0f;
+          if (ok) {
+            if (b < a.rows_in) d = acc[tm][tn][reg] + a.dhz_in[o];
+            else if (a.inject) d = a.inject[o];
+            if (!a.final_step) {
+              if (a.dout) d += a.dout[o];
+              r[q] = to_f32<T>(a.sv_r[o]); z[q] = to_f32<T>(a.sv_z[o]); n[q] = to_f32<T>(a.sv_n[o]);
+              hn[q] = to_f32<T>(a.sv_hn[o]); hp[q] = to_f32<T>(a.sv_hprev[o]);
+            } else if (a.dh0_accumulate) {
+              d += a.dh0[o];
+            }
+          }
+          dh[q] = d;
         }
-        if (a.dout) dh += a.dout[o];
-        const float r = to_f32<T>(a.sv_r[o]), z = to_f32<T>(a.sv_z[o]), n = to_f32<T>(a.sv_n[o]);
-        const float hn = to_f32<T>(a.sv_hn[o]), hp = to_f32<T>(a.sv_hprev[o]);
-        const float dnp = dh * (1.0f - z) * (1.0f - n * n);
-        const float dzp = dh * (hp - n) * z * (1.0f - z);
-        const float drp = dnp * hn * r * (1.0f - r);
-        const long og = (long)b * 3 * H + j;
-        a.dGI[og] = from_f32<T>(drp);
-        a.dGI[og + H] = from_f32<T>(dzp);
-        a.dGI[og + 2 * H] = from_f32<T>(dnp);
-        a.dGH[og] = from_f32<T>(drp);
-        a.dGH[og + H] = from_f32<T>(dzp);
-        a.dGH[og + 2 * H] = from_f32<T>(dnp * r);
-        a.dhz_out[o] = dh * z;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int reg = half * 8 + q;
+          const int b = m0 + Cfg::row_of(wm, tm, reg, lane);
+          const bool ok = jok && b < a.rows_out;
+          if (!ok) continue;
+          const long o = (long)b * H + j;
+          if (a.final_step) {
+            a.dh0[o] = dh[q];
+            continue;
+          }
+          const float dnp = dh[q] * (1.0f - z[q]) * (1.0f - n[q] * n[q]);
+          const float dzp = dh[q] * (hp[q] - n[q]) * z[q] * (1.0f - z[q]);
+          const float drp = dnp * hn[q] * r[q] * (1.0f - r[q]);
+          const long og = (long)b * 3 * H + j;
+          a.dGI[og] = from_f32<T>(drp);
+          a.dGI[og + H] = from_f32<T>(dzp);
+          a.dGI[og + 2 * H] = from_f32<T>(dnp);
+          a.dGH[og] = from_f32<T>(drp);
+          a.dGH[og + H] = from_f32<T>(dzp);
+          a.dGH[og + 2 * H] = from_f32<T>(dnp * r[q]);
+          a.dhz_out[o] = dh[q] * z[q];
+        }
       }
   }
+}
+
+// ================================================================================================
+// v2 step kernels for the training regime (rows <= a few thousand): latency-optimised.
+//   * block = G K-groups x 4 waves; every group contracts 1/G of K into its own LDS staging region, all groups' loads
+//     are in flight together (the step is latency-bound: few blocks, short K loop);
+//   * accumulators are exchanged / reduced through LDS as fp32 tiles, then EVERY thread runs the gate epilogue on
+//     8 consecutive columns of one row with 16-byte loads and stores (instead of 2-byte lane-per-column accesses);
+//   * the epilogue's inputs are fetched before the main loop, so their latency hides under it.
+// ================================================================================================
+template <typename T> struct Vec8;
+template <> struct Vec8<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+template <> struct Vec8<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    const bf16x8 x = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)x[i];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    bf16x8 x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = x;
+  }
+};
+__device__ __forceinline__ void zero8(float (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = 0.0f;
+}
+
+constexpr int V2_BM = 64, V2_BH = 64, V2_LD = 68;   // exchange tile row stride in floats (272 B: 16-B aligned rows)
+
+// writes / accumulates the wave's 32x32 accumulator tiles into the fp32 exchange tiles xt[slot][64][V2_LD]
+template <class Cfg, int NACC>
+__device__ __forceinline__ void v2_exchange(f32x16 (&acc)[Cfg::TM][NACC], float* xt, int gtid, int group, int G) {
+  const int lane = gtid & 63, wave = gtid >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  for (int g = 0; g < G; ++g) {
+    if (group == g) {
+#pragma unroll
+      for (int s = 0; s < NACC; ++s)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          float* p = xt + (s * V2_BM + Cfg::row_of(wm, 0, reg, lane)) * V2_LD + wn * 32 + (lane & 31);
+          if (g == 0) *p = acc[0][s][reg];
+          else *p += acc[0][s][reg];
+        }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T, int MODE, int G, int D>
+__global__ __launch_bounds__(256 * G) void gru_fwd2_kernel(GruFwdArgs<T> a) {
+  using Cfg = TileCfg<T, V2_BM, 3 * V2_BH, 8, 2, 2, 3, D>;
+  static_assert(Cfg::TM == 1 && Cfg::TU == 1, "v2 geometry");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NACC = MODE == PG_GI_FUSED ? 4 : 3;
+  constexpr int NTH = 256 * G;
+  const int H = a.H;
+  const int j0 = blockIdx.x * V2_BH, m0 = blockIdx.y * V2_BM;
+  const int tid = threadIdx.x, group = tid >> 8, gtid = tid & 255;
+  // ---- epilogue assignment + input prefetch: chunk c covers row c/8, columns 8*(c%8)..+7 of the 64x64 tile
+  constexpr int CH = (V2_BM * V2_BH / 8 + NTH - 1) / NTH;
+  float gr[CH][8], gz[CH][8], gn[CH][8], hp[CH][8];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int id = tid + c * NTH;
+    const int b = m0 + id / 8, j = j0 + (id % 8) * 8;
+    zero8(gr[c]); zero8(gz[c]); zero8(gn[c]); zero8(hp[c]);
+    if (id < V2_BM * V2_BH / 8 && b < a.rows && j < H) {
+      if (MODE == PG_GI_ARRAY) {
+        const float* g = a.gi + (long)b * 3 * H + j;
+        Vec8<float>::load(g, gr[c]); Vec8<float>::load(g + H, gz[c]); Vec8<float>::load(g + 2 * H, gn[c]);
+      } else if (MODE == PG_GI_TABLE) {
+        const float* g = a.table + (long)a.tok[b] * 3 * H + j;
+        Vec8<float>::load(g, gr[c]); Vec8<float>::load(g + H, gz[c]); Vec8<float>::load(g + 2 * H, gn[c]);
+        if (a.zproj) {
+          float t0[8], t1[8], t2[8];
+          const float* zp = a.zproj + (long)b * 3 * H + j;
+          Vec8<float>::load(zp, t0); Vec8<float>::load(zp + H, t1); Vec8<float>::load(zp + 2 * H, t2);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { gr[c][i] += t0[i]; gz[c][i] += t1[i]; gn[c][i] += t2[i]; }
+        }
+      } else {
+        Vec8<float>::load(a.bias_gi + j, gr[c]); Vec8<float>::load(a.bias_gi + H + j, gz[c]);
+        Vec8<float>::load(a.bias_gi + 2 * H + j, gn[c]);
+      }
+      if (a.hprev32) Vec8<float>::load(a.hprev32 + (long)b * H + j, hp[c]);
+    }
+  }
+  // ---- gate GEMM, K split over the G groups
+  f32x16 acc[1][NACC];
+  {
+    const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NACC; ++s) acc[0][s] = zacc;
+  }
+  char* gsm = smem + group * Cfg::SMEM_BYTES;
+  if (a.hprev_op) {
+    const int nkg = ((H + Cfg::BK - 1) / Cfg::BK + G - 1) / G;
+    RowSrc<T> as{a.hprev_op, H, m0, a.rows};
+    GateRowSrc<T> bs{a.Whh, H, H, j0, V2_BH};
+    mma_mainloop_nt<Cfg, NACC, 2>(acc, as, bs, H, gsm, gtid, group * nkg, nkg);
+  }
+  if (MODE == PG_GI_FUSED) {
+    const int nkg = ((a.Kx + Cfg::BK - 1) / Cfg::BK + G - 1) / G;
+    RowSrc<T> as{a.x, a.Kx, m0, a.rows};
+    GateRowSrc<T> bs{a.Wih, a.Kx, H, j0, V2_BH};
+    mma_mainloop_nt<Cfg, NACC, 3>(acc, as, bs, a.Kx, gsm, gtid, group * nkg, nkg);
+  }
+  float* xt = reinterpret_cast<float*>(smem);
+  v2_exchange<Cfg, NACC>(acc, xt, gtid, group, G);
+  // ---- wide epilogue
+  const float inv_keep = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int id = tid + c * NTH;
+    const int row = id / 8, col = (id % 8) * 8;
+    const int b = m0 + row, j = j0 + col;
+    if (!(id < V2_BM * V2_BH / 8 && b < a.rows && j < H)) continue;
+    float ar[8], az[8], ahn[8], ain[8], bhn[8];
+    Vec8<float>::load(xt + (0 * V2_BM + row) * V2_LD + col, ar);
+    Vec8<float>::load(xt + (1 * V2_BM + row) * V2_LD + col, az);
+    Vec8<float>::load(xt + (2 * V2_BM + row) * V2_LD + col, ahn);
+    if (MODE == PG_GI_FUSED) Vec8<float>::load(xt + (3 * V2_BM + row) * V2_LD + col, ain);
+    Vec8<float>::load(a.bhn + j, bhn);
+    float h[8], r[8], z[8], n[8], hn[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      r[i] = sigmoidf_(gr[c][i] + ar[i]);
+      z[i] = sigmoidf_(gz[c][i] + az[i]);
+      hn[i] = ahn[i] + bhn[i];
+      const float gnn = MODE == PG_GI_FUSED ? gn[c][i] + ain[i] : gn[c][i];
+      n[i] = tanhf_(gnn + r[i] * hn[i]);
+      h[i] = (1.0f - z[i]) * n[i] + z[i] * hp[c][i];
+    }
+    const long o = (long)b * H + j;
+    Vec8<float>::store(a.h32 + o, h);
+    Vec8<T>::store(a.h_op + o, h);
+    if (a.sv_r) {
+      Vec8<T>::store(a.sv_r + o, r); Vec8<T>::store(a.sv_z + o, z); Vec8<T>::store(a.sv_n + o, n);
+      Vec8<T>::store(a.sv_hn + o, hn); Vec8<T>::store(a.sv_hprev + o, hp[c]);
+    }
+    if (a.h_drop) {
+      float hd[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        hd[i] = h[i] * dropout_scale(a.seed, a.layer, a.t, b * a.b_mul + a.b_add, j + i, a.p_drop, inv_keep);
+      Vec8<T>::store(a.h_drop + o, hd);
+    }
+  }
+}
+
+template <typename T, int G, int D>
+__global__ __launch_bounds__(256 * G) void gru_bwd2_kernel(GruBwdArgs<T> a) {
+  using Cfg = TileCfg<T, V2_BM, V2_BH, 8, 2, 2, 1, D>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NTH = 256 * G;
+  const int H = a.H;
+  const int j0 = blockIdx.x * V2_BH, m0 = blockIdx.y * V2_BM;
+  const int tid = threadIdx.x, group = tid >> 8, gtid = tid & 255;
+  constexpr int CH = (V2_BM * V2_BH / 8 + NTH - 1) / NTH;
+  float dh[CH][8], r[CH][8], z[CH][8], n[CH][8], hn[CH][8], hp[CH][8];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int id = tid + c * NTH;
+    const int b = m0 + id / 8, j = j0 + (id % 8) * 8;
+    zero8(dh[c]); zero8(r[c]); zero8(z[c]); zero8(n[c]); zero8(hn[c]); zero8(hp[c]);
+    if (id < V2_BM * V2_BH / 8 && b < a.rows_out && j < H) {
+      const long o = (long)b * H + j;
+      if (b < a.rows_in) Vec8<float>::load(a.dhz_in + o, dh[c]);
+      else if (a.inject) Vec8<float>::load(a.inject + o, dh[c]);
+      float t[8];
+      if (!a.final_step) {
+        if (a.dout) {
+          Vec8<float>::load(a.dout + o, t);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) dh[c][i] += t[i];
+        }
+        Vec8<T>::load(a.sv_r + o, r[c]); Vec8<T>::load(a.sv_z + o, z[c]); Vec8<T>::load(a.sv_n + o, n[c]);
+        Vec8<T>::load(a.sv_hn + o, hn[c]); Vec8<T>::load(a.sv_hprev + o, hp[c]);
+      } else if (a.dh0_accumulate) {
+        Vec8<float>::load(a.dh0 + o, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dh[c][i] += t[i];
+      }
+    }
+  }
+  f32x16 acc[1][1];
+  {
+    const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    acc[0][0] = zacc;
+  }
+  if (a.rows_in > 0 && m0 < a.rows_in) {   // block-uniform
+    const int nkg = ((3 * H + Cfg::BK - 1) / Cfg::BK + G - 1) / G;
+    RowSrc<T> as{a.dGH_in, 3L * H, m0, a.rows_in};
+    RowSrc<T> bs{a.WhhT, 3L * H, j0, H};
+    mma_mainloop_nt<Cfg, 1, 0>(acc, as, bs, 3 * H, smem + group * Cfg::SMEM_BYTES, gtid, group * nkg, nkg);
+  }
+  float* xt = reinterpret_cast<float*>(smem);
+  v2_exchange<Cfg, 1>(acc, xt, gtid, group, G);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int id = tid + c * NTH;
+    const int row = id / 8, col = (id % 8) * 8;
+    const int b = m0 + row, j = j0 + col;
+    if (!(id < V2_BM * V2_BH / 8 && b < a.rows_out && j < H)) continue;
+    float ac[8];
+    Vec8<float>::load(xt + row * V2_LD + col, ac);
+    const long o = (long)b * H + j;
+    if (b < a.rows_in) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dh[c][i] += ac[i];
+    }
+    if (a.final_step) {
+      Vec8<float>::store(a.dh0 + o, dh[c]);
+      continue;
+    }
+    float drp[8], dzp[8], dnp[8], dnr[8], dhz[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      dnp[i] = dh[c][i] * (1.0f - z[c][i]) * (1.0f - n[c][i] * n[c][i]);
+      dzp[i] = dh[c][i] * (hp[c][i] - n[c][i]) * z[c][i] * (1.0f - z[c][i]);
+      drp[i] = dnp[i] * hn[c][i] * r[c][i] * (1.0f - r[c][i]);
+      dnr[i] = dnp[i] * r[c][i];
+      dhz[i] = dh[c][i] * z[c][i];
+    }
+    const long og = (long)b * 3 * H + j;
+    Vec8<T>::store(a.dGI + og, drp); Vec8<T>::store(a.dGI + og + H, dzp); Vec8<T>::store(a.dGI + og + 2 * H, dnp);
+    Vec8<T>::store(a.dGH + og, drp); Vec8<T>::store(a.dGH + og + H, dzp); Vec8<T>::store(a.dGH + og + 2 * H, dnr);
+    Vec8<float>::store(a.dhz_out + o, dhz);
+  }
+}
+
+template <int MODE, int G, int D, typename T> static int launch_fwd2(const GruFwdArgs<T>& a, hipStream_t stream) {
+  using Cfg = TileCfg<T, V2_BM, 3 * V2_BH, 8, 2, 2, 3, D>;
+  constexpr size_t smem = (size_t)G * Cfg::SMEM_BYTES;
+  static_assert(smem >= 4 * V2_BM * V2_LD * 4, "exchange tiles must fit the staging LDS");
+  dim3 grid(cdiv(a.H, V2_BH), cdiv(a.rows, V2_BM));
+  PG_LAUNCH_BIG_SMEM((gru_fwd2_kernel<T, MODE, G, D>), grid, dim3(256 * G), smem, stream, a);
+  PG_CHECK_LAUNCH();
+  return PG_OK;
+}
+template <int G, int D, typename T> static int launch_bwd2(const GruBwdArgs<T>& a, hipStream_t stream) {
+  using Cfg = TileCfg<T, V2_BM, V2_BH, 8, 2, 2, 1, D>;
+  constexpr size_t smem = (size_t)G * Cfg::SMEM_BYTES;
+  static_assert(smem >= V2_BM * V2_LD * 4, "exchange tile must fit the staging LDS");
+  dim3 grid(cdiv(a.H, V2_BH), cdiv(a.rows_out, V2_BM));
+  PG_LAUNCH_BIG_SMEM((gru_bwd2_kernel<T, G, D>), grid, dim3(256 * G), smem, stream, a);
+  PG_CHECK_LAUNCH();
+  return PG_OK;
 }
 
 template <class Cfg, int MODE, typename T> static int launch_fwd_cfg(const GruFwdArgs<T>& a, hipStream_t stream) {
@@ -170,10 +468,10 @@ template <typename T> int launch_gru_fwd(const GruFwdArgs<T>& a, hipStream_t str
     if (a.gi_mode == PG_GI_TABLE) return launch_fwd_cfg<Cfg, PG_GI_TABLE, T>(a, stream);
     return launch_fwd_cfg<Cfg, PG_GI_FUSED, T>(a, stream);
   }
-  using Cfg = TileCfg<T, 64, 192, 8, 2, 2, 3>;
-  if (a.gi_mode == PG_GI_ARRAY) return launch_fwd_cfg<Cfg, PG_GI_ARRAY, T>(a, stream);
-  if (a.gi_mode == PG_GI_TABLE) return launch_fwd_cfg<Cfg, PG_GI_TABLE, T>(a, stream);
-  return launch_fwd_cfg<Cfg, PG_GI_FUSED, T>(a, stream);
+  PG_REQUIRE(a.H % 8 == 0, "gru_fwd: hidden size must be a multiple of 8");
+  if (a.gi_mode == PG_GI_ARRAY) return launch_fwd2<PG_GI_ARRAY, 2, 2, T>(a, stream);
+  if (a.gi_mode == PG_GI_TABLE) return launch_fwd2<PG_GI_TABLE, 2, 2, T>(a, stream);
+  return launch_fwd2<PG_GI_FUSED, 2, 2, T>(a, stream);
 }
 
 template <typename T> int launch_gru_bwd(const GruBwdArgs<T>& a, hipStream_t stream) {
@@ -181,7 +479,8 @@ template <typename T> int launch_gru_bwd(const GruBwdArgs<T>& a, hipStream_t str
   if (a.rows_out <= 0) return PG_OK;
   PG_REQUIRE(a.H % EPC == 0, "gru_bwd: hidden size %d must be a multiple of %d", a.H, EPC);
   PG_REQUIRE(a.rows_in <= a.rows_out, "gru_bwd: rows_in %d > rows_out %d (batch must be sorted by length)", a.rows_in, a.rows_out);
-  using Cfg = TileCfg<T, 64, 64, 8, 2, 2, 1>;
+  if (a.rows_out <= 4096) return launch_bwd2<4, 2, T>(a, stream);
+  using Cfg = TileCfg<T, 64, 64, 8, 2, 2, 1, 4>;
   dim3 grid(cdiv(a.H, Cfg::BN), cdiv(a.rows_out, Cfg::BM));
   PG_LAUNCH_BIG_SMEM(gru_bwd_kernel<Cfg>, grid, dim3(Cfg::NTHREADS), Cfg::SMEM_BYTES, stream, a);
   PG_CHECK_LAUNCH();

@@ -12,6 +12,27 @@
 #pragma once
 #include "pg_common.h"
 
+template <int I> struct IntC { static constexpr int value = I; };
+template <int N, int I = 0, class F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(IntC<I>{});
+    static_for<N, I + 1>(f);
+  }
+}
+
+// Branch-free predicated 16-byte global load: a raw buffer descriptor over [base, base + 2 GiB) and a per-lane byte
+// offset; lanes that must not load pass PG_OOB, which the hardware range check turns into zeros (no branch, so hipcc
+// keeps counted vmcnt waits and the register prefetch ring really stays in flight).
+#define PG_OOB 0xFFFFFFF0u
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pg_make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ uint4 pg_buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 template <typename T> struct MmaOp;
 template <> struct MmaOp<bf16_t> {
   static __device__ __forceinline__ void run(f32x16& c, const uint4& a, const uint4& b) {
@@ -48,9 +69,10 @@ template <typename T> struct GateRowSrc {
   }
 };
 
-template <typename T_, int BM_, int BN_, int BKC_, int WM_, int WN_, int NGATE_ = 1> struct TileCfg {
+template <typename T_, int BM_, int BN_, int BKC_, int WM_, int WN_, int NGATE_ = 1, int DEPTH_ = 1> struct TileCfg {
   using T = T_;
   static constexpr int BM = BM_, BN = BN_, BKC = BKC_, WM = WM_, WN = WN_, NGATE = NGATE_;
+  static constexpr int DEPTH = DEPTH_;         // K tiles kept in flight in registers (global-load prefetch depth)
   static constexpr int NTHREADS = 64 * WM * WN;
   static constexpr int EPC = 16 / sizeof(T);   // elements per 16-byte chunk
   static constexpr int BK = BKC * EPC;         // K elements per tile
@@ -80,14 +102,16 @@ template <typename T_, int BM_, int BN_, int BKC_, int WM_, int WN_, int NGATE_ 
 // second pass route the n-gate to a separate accumulator).  Leaves the block synchronised (LDS reusable).
 template <class Cfg, int NACC, int SLOT_LAST, class ASrc, class BSrc>
 __device__ __forceinline__ void mma_mainloop_nt(f32x16 (&acc)[Cfg::TM][NACC], const ASrc& asrc, const BSrc& bsrc,
-                                                int K, char* smem) {
+                                                int K, char* smem, int tid, int kt_begin, int nk) {
+  // tid: thread index inside the K-group (Cfg::NTHREADS threads share `smem`); the group contracts K tiles
+  // kt_begin .. kt_begin+nk-1.  Every K-group of a block must pass the same nk (the barriers are block-wide).
   using T = typename Cfg::T;
   constexpr int NT = Cfg::NTHREADS, BKC = Cfg::BKC, EPC = Cfg::EPC, ROWB = Cfg::ROWB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
-  const T* __restrict__ abase = asrc.base;
-  const T* __restrict__ bbase = bsrc.base;
-  long pa[Cfg::A_IT], pb[Cfg::B_IT];
+  const __amdgpu_buffer_rsrc_t arsrc = pg_make_rsrc(asrc.base);
+  const __amdgpu_buffer_rsrc_t brsrc = pg_make_rsrc(bsrc.base);
+  unsigned pa[Cfg::A_IT], pb[Cfg::B_IT];   // per-lane byte offset of its chunk at k = 0 (PG_OOB: never loads)
   int oa[Cfg::A_IT], ob[Cfg::B_IT];
 #pragma unroll
   for (int i = 0; i < Cfg::A_IT; ++i) {
@@ -95,7 +119,7 @@ __device__ __forceinline__ void mma_mainloop_nt(f32x16 (&acc)[Cfg::TM][NACC], co
     int row = id / BKC, c = id % BKC;
     bool ok = id < Cfg::BM * BKC;
     long o = ok ? asrc(row) : -1L;
-    pa[i] = o >= 0 ? o + c * EPC : -1L;
+    pa[i] = o >= 0 ? (unsigned)((o + c * EPC) * (long)sizeof(T)) : PG_OOB;
     oa[i] = ok ? row * ROWB + c * 16 : -1;
   }
 #pragma unroll
@@ -104,37 +128,38 @@ __device__ __forceinline__ void mma_mainloop_nt(f32x16 (&acc)[Cfg::TM][NACC], co
     int row = id / BKC, c = id % BKC;
     bool ok = id < Cfg::BN * BKC;
     long o = ok ? bsrc(row) : -1L;
-    pb[i] = o >= 0 ? o + c * EPC : -1L;
+    pb[i] = o >= 0 ? (unsigned)((o + c * EPC) * (long)sizeof(T)) : PG_OOB;
     ob[i] = ok ? row * ROWB + c * 16 : -1;
   }
-  uint4 ra[Cfg::A_IT], rb[Cfg::B_IT];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
-  const int nk = (K + Cfg::BK - 1) / Cfg::BK;
-  // k0 >= K on the (dummy) prefetch of the last iteration: every chunk is then predicated off
-  auto gload = [&](int kt) __attribute__((always_inline)) {
-    const int k0 = kt * Cfg::BK;
+  constexpr int D = Cfg::DEPTH;
+  uint4 ra[D][Cfg::A_IT], rb[D][Cfg::B_IT];   // register ring: tile j lives in slot j % D (static indices only)
+  const int kend = min(K, (kt_begin + nk) * Cfg::BK);   // this K-group's end: nothing is fetched past it
+  // chunks past kend (and whole tiles past the last one) get PG_OOB: zeros, no memory traffic, no branch
+  auto gload = [&](int kt, auto slot_c) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slot_c)::value;
+    const int k0 = (kt_begin + kt) * Cfg::BK;
+    const unsigned soff = (unsigned)k0 * (unsigned)sizeof(T);
 #pragma unroll
     for (int i = 0; i < Cfg::A_IT; ++i) {
       int c = (tid + i * NT) % BKC;
-      ra[i] = zero4;
-      if (pa[i] >= 0 && k0 + c * EPC < K) ra[i] = *reinterpret_cast<const uint4*>(abase + pa[i] + k0);
+      ra[slot][i] = pg_buf_load16(arsrc, (k0 + c * EPC < kend) ? pa[i] : PG_OOB, soff);
     }
 #pragma unroll
     for (int i = 0; i < Cfg::B_IT; ++i) {
       int c = (tid + i * NT) % BKC;
-      rb[i] = zero4;
-      if (pb[i] >= 0 && k0 + c * EPC < K) rb[i] = *reinterpret_cast<const uint4*>(bbase + pb[i] + k0);
+      rb[slot][i] = pg_buf_load16(brsrc, (k0 + c * EPC < kend) ? pb[i] : PG_OOB, soff);
     }
   };
-  auto sstore = [&](int buf) __attribute__((always_inline)) {
+  auto sstore = [&](int buf, auto slot_c) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slot_c)::value;
     char* sa = smem + buf * Cfg::STAGE_BYTES;
     char* sb = sa + Cfg::A_BYTES;
 #pragma unroll
     for (int i = 0; i < Cfg::A_IT; ++i)
-      if (oa[i] >= 0) *reinterpret_cast<uint4*>(sa + oa[i]) = ra[i];
+      if (oa[i] >= 0) *reinterpret_cast<uint4*>(sa + oa[i]) = ra[slot][i];
 #pragma unroll
     for (int i = 0; i < Cfg::B_IT; ++i)
-      if (ob[i] >= 0) *reinterpret_cast<uint4*>(sb + ob[i]) = rb[i];
+      if (ob[i] >= 0) *reinterpret_cast<uint4*>(sb + ob[i]) = rb[slot][i];
   };
   const int lr = lane & 31, lh = lane >> 5;
   auto compute = [&](int buf) __attribute__((always_inline)) {
@@ -161,15 +186,28 @@ __device__ __forceinline__ void mma_mainloop_nt(f32x16 (&acc)[Cfg::TM][NACC], co
         }
     }
   };
-  gload(0);
-  sstore(0);
+  // prologue: tiles 0..D-1 in flight, tile 0 staged
+  static_for<D>([&](auto d) __attribute__((always_inline)) { gload(decltype(d)::value, d); });
+  sstore(0, IntC<0>{});
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    gload(kt + 1);   // the last one is fully predicated off (zeros into the idle buffer)
-    compute(kt & 1);
-    sstore((kt + 1) & 1);
-    __syncthreads();
+  for (int kt0 = 0; kt0 < nk; kt0 += D) {
+    static_for<D>([&](auto d) __attribute__((always_inline)) {
+      constexpr int dd = decltype(d)::value;
+      const int kt = kt0 + dd;
+      if (kt < nk) {                               // block-uniform
+        gload(kt + D, d);                          // slot dd was staged one iteration ago: refill it
+        compute(kt & 1);
+        sstore((kt + 1) & 1, IntC<(dd + 1) % D>{});  // tile kt+1 (oldest loads in flight) -> idle LDS buffer
+        __syncthreads();
+      }
+    });
   }
+}
+
+template <class Cfg, int NACC, int SLOT_LAST, class ASrc, class BSrc>
+__device__ __forceinline__ void mma_mainloop_nt(f32x16 (&acc)[Cfg::TM][NACC], const ASrc& asrc, const BSrc& bsrc,
+                                                int K, char* smem) {
+  mma_mainloop_nt<Cfg, NACC, SLOT_LAST>(acc, asrc, bsrc, K, smem, (int)threadIdx.x, 0, (K + Cfg::BK - 1) / Cfg::BK);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -237,7 +275,9 @@ __device__ __forceinline__ void mma_mainloop_tn(f32x16 (&acc)[Cfg::TM][Cfg::TN],
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   uint4 ra[Cfg::A_IT], rb[Cfg::B_IT];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  // descriptors start at this block's first row (r0) so that 32-bit byte offsets cover any split of a long operand
+  const __amdgpu_buffer_rsrc_t arsrc = pg_make_rsrc(A + (long)r0 * lda);
+  const __amdgpu_buffer_rsrc_t brsrc = pg_make_rsrc(B + (long)r0 * ldb);
   const int nk = (r1 - r0 + Cfg::BKR - 1) / Cfg::BKR;
   auto gload = [&](int kt) __attribute__((always_inline)) {
     const int rr = r0 + kt * Cfg::BKR;
@@ -245,15 +285,13 @@ __device__ __forceinline__ void mma_mainloop_tn(f32x16 (&acc)[Cfg::TM][Cfg::TN],
     for (int i = 0; i < Cfg::A_IT; ++i) {
       int id = tid + i * NT, kr = id / Cfg::ACH, c = id % Cfg::ACH;
       bool ok = id < Cfg::BKR * Cfg::ACH && rr + kr < r1 && m0 + c * EPC < Mtot;
-      ra[i] = zero4;
-      if (ok) ra[i] = *reinterpret_cast<const uint4*>(A + (long)(rr + kr) * lda + m0 + c * EPC);
+      ra[i] = pg_buf_load16(arsrc, ok ? (unsigned)(((long)(rr + kr - r0) * lda + m0 + c * EPC) * (long)sizeof(T)) : PG_OOB, 0);
     }
 #pragma unroll
     for (int i = 0; i < Cfg::B_IT; ++i) {
       int id = tid + i * NT, kr = id / Cfg::BCH, c = id % Cfg::BCH;
       bool ok = id < Cfg::BKR * Cfg::BCH && rr + kr < r1 && n0 + c * EPC < Ntot;
-      rb[i] = zero4;
-      if (ok) rb[i] = *reinterpret_cast<const uint4*>(B + (long)(rr + kr) * ldb + n0 + c * EPC);
+      rb[i] = pg_buf_load16(brsrc, ok ? (unsigned)(((long)(rr + kr - r0) * ldb + n0 + c * EPC) * (long)sizeof(T)) : PG_OOB, 0);
     }
   };
   auto sstore = [&](int buf) __attribute__((always_inline)) {

@@ -56,24 +56,26 @@ def test_dropout_mask_consistent_between_forward_and_backward():
     batch = model.get_collate_fn()(O.synthetic_smiles(16, seed=9))
     eng = model._engine
     opt = FusedClipAdam(model, lr=0.0)
-    eps = torch.randn(16, TINY["Dz"], device="cuda")
+    eps = torch.from_numpy(np.random.default_rng(4).standard_normal((16, TINY["Dz"])).astype(np.float32)).cuda()
 
     def loss_at():
         kl, rec = eng.train_step(batch, 0.3, opt.flat_grad, eps=eps, p_drop=0.3, seed=77)
         return (0.3 * kl + rec).item()
-    loss_at()
+    l0 = loss_at()
     g = opt.flat_grad.clone()
-    d = torch.randn_like(g)
-    d /= d.norm()
+    for _ in range(5):      # the forward is atomics-free apart from the loss sums: repeated calls must agree closely
+        assert abs(loss_at() - l0) <= 1e-5 * abs(l0)
+        assert (opt.flat_grad - g).abs().max().item() <= 1e-4 * g.abs().max().item()
+    d = g / g.norm()          # steepest direction: directional derivative = |g|, well above fp32 noise
     flat = eng.ensure_flat()
-    h = 1e-2
+    h = 2e-3
     with torch.no_grad():
         flat.add_(d, alpha=h); eng.invalidate(); lp = loss_at()
         flat.add_(d, alpha=-2 * h); eng.invalidate(); lm = loss_at()
         flat.add_(d, alpha=h); eng.invalidate()
     fd = (lp - lm) / (2 * h)
     an = float((g * d).sum())
-    assert abs(fd - an) <= 5e-2 * max(abs(an), 1e-3), (fd, an)
+    assert abs(fd - an) <= 2e-2 * abs(an), (fd, an)
     # and dropout actually drops: loss differs from the p=0 loss
     kl, rec = eng.train_step(batch, 0.3, opt.flat_grad, eps=eps, p_drop=0.0, seed=77)
     assert abs((0.3 * kl + rec).item() - loss_at()) > 1e-4
