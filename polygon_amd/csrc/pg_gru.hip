@@ -1,4 +1,5 @@
 // GRU recurrent step kernels for gfx950: gate GEMM on MFMA + fused gate (or gate-gradient) epilogue.
+#include <stdlib.h>
 #include "pg_gru.h"
 #include "pg_mma.h"
 
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256 * G) void gru_fwd2_kernel(GruFwdArgs<T> a) {
     const int id = tid + c * NTH;
     const int b = m0 + id / 8, j = j0 + (id % 8) * 8;
     zero8(gr[c]); zero8(gz[c]); zero8(gn[c]); zero8(hp[c]);
-    if (id < V2_BM * V2_BH / 8 && b < a.rows && j < H) {
+    if (id < V2_BM * V2_BH / 8 && b < a.rows && j < H && !(a.dbg & 4)) {
       if (MODE == PG_GI_ARRAY) {
         const float* g = a.gi + (long)b * 3 * H + j;
         Vec8<float>::load(g, gr[c]); Vec8<float>::load(g + H, gz[c]); Vec8<float>::load(g + 2 * H, gn[c]);
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256 * G) void gru_fwd2_kernel(GruFwdArgs<T> a) {
     for (int s = 0; s < NACC; ++s) acc[0][s] = zacc;
   }
   char* gsm = smem + group * Cfg::SMEM_BYTES;
-  if (a.hprev_op) {
+  if (a.hprev_op && !(a.dbg & 1)) {
     const int nkg = ((H + Cfg::BK - 1) / Cfg::BK + G - 1) / G;
     RowSrc<T> as{a.hprev_op, H, m0, a.rows};
     GateRowSrc<T> bs{a.Whh, H, H, j0, V2_BH};
@@ -307,7 +308,9 @@ __global__ __launch_bounds__(256 * G) void gru_fwd2_kernel(GruFwdArgs<T> a) {
     mma_mainloop_nt<Cfg, NACC, 3>(acc, as, bs, a.Kx, gsm, gtid, group * nkg, nkg);
   }
   float* xt = reinterpret_cast<float*>(smem);
+  if (a.dbg & 2) { if (acc[0][0][0] == 123.456f || gr[0][0] == 77.7f) a.h32[0] = 1.0f; return; }
   v2_exchange<Cfg, NACC>(acc, xt, gtid, group, G);
+  if (a.dbg & 8) { if (xt[tid] == 123.456f) a.h32[0] = 1.0f; return; }
   // ---- wide epilogue
   const float inv_keep = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
 #pragma unroll
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(256 * G) void gru_bwd2_kernel(GruBwdArgs<T> a) {
     const int id = tid + c * NTH;
     const int b = m0 + id / 8, j = j0 + (id % 8) * 8;
     zero8(dh[c]); zero8(r[c]); zero8(z[c]); zero8(n[c]); zero8(hn[c]); zero8(hp[c]);
-    if (id < V2_BM * V2_BH / 8 && b < a.rows_out && j < H) {
+    if (id < V2_BM * V2_BH / 8 && b < a.rows_out && j < H && !(a.dbg & 4)) {
       const long o = (long)b * H + j;
       if (b < a.rows_in) Vec8<float>::load(a.dhz_in + o, dh[c]);
       else if (a.inject) Vec8<float>::load(a.inject + o, dh[c]);
@@ -389,14 +392,16 @@ __global__ __launch_bounds__(256 * G) void gru_bwd2_kernel(GruBwdArgs<T> a) {
     const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     acc[0][0] = zacc;
   }
-  if (a.rows_in > 0 && m0 < a.rows_in) {   // block-uniform
+  if (a.rows_in > 0 && m0 < a.rows_in && !(a.dbg & 1)) {   // block-uniform
     const int nkg = ((3 * H + Cfg::BK - 1) / Cfg::BK + G - 1) / G;
     RowSrc<T> as{a.dGH_in, 3L * H, m0, a.rows_in};
     RowSrc<T> bs{a.WhhT, 3L * H, j0, H};
     mma_mainloop_nt<Cfg, 1, 0>(acc, as, bs, 3 * H, smem + group * Cfg::SMEM_BYTES, gtid, group * nkg, nkg);
   }
   float* xt = reinterpret_cast<float*>(smem);
+  if (a.dbg & 2) { if (acc[0][0][0] == 123.456f || dh[0][0] == 77.7f) a.dhz_out[0] = 1.0f; return; }
   v2_exchange<Cfg, 1>(acc, xt, gtid, group, G);
+  if (a.dbg & 8) { if (xt[tid] == 123.456f) a.dhz_out[0] = 1.0f; return; }
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int id = tid + c * NTH;
@@ -462,13 +467,35 @@ template <typename T> int launch_gru_fwd(const GruFwdArgs<T>& a, hipStream_t str
   PG_REQUIRE(a.H % EPC == 0 && a.H >= 32, "gru_fwd: hidden size %d must be a multiple of %d", a.H, EPC);
   PG_REQUIRE(a.gi_mode != PG_GI_FUSED || (a.Kx % EPC == 0), "gru_fwd: fused input width %d must be a multiple of %d", a.Kx, EPC);
   PG_REQUIRE((a.hprev_op == nullptr) == (a.hprev32 == nullptr), "gru_fwd: hprev_op / hprev32 must both be set or null");
-  if (a.rows > 2048) {
-    using Cfg = TileCfg<T, 128, 192, 4, 2, 2, 3>;
+  static const int variant = getenv("PG_FWD_VARIANT") ? atoi(getenv("PG_FWD_VARIANT")) : 0;   // tuning aid
+  if (variant == 1 || variant == 2) {
+    if (variant == 1) {
+      if (a.gi_mode == PG_GI_ARRAY) return launch_fwd2<PG_GI_ARRAY, 1, 2, T>(a, stream);
+      if (a.gi_mode == PG_GI_TABLE) return launch_fwd2<PG_GI_TABLE, 1, 2, T>(a, stream);
+      return launch_fwd2<PG_GI_FUSED, 1, 2, T>(a, stream);
+    }
+    if (a.gi_mode == PG_GI_ARRAY) return launch_fwd2<PG_GI_ARRAY, 2, 2, T>(a, stream);
+    if (a.gi_mode == PG_GI_TABLE) return launch_fwd2<PG_GI_TABLE, 2, 2, T>(a, stream);
+    return launch_fwd2<PG_GI_FUSED, 2, 2, T>(a, stream);
+  }
+  if (variant == 3) {
+    using Cfg = TileCfg<T, 128, 192, 4, 2, 2, 3, 2>;
+    if (a.gi_mode == PG_GI_ARRAY) return launch_fwd_cfg<Cfg, PG_GI_ARRAY, T>(a, stream);
+    if (a.gi_mode == PG_GI_TABLE) return launch_fwd_cfg<Cfg, PG_GI_TABLE, T>(a, stream);
+    return launch_fwd_cfg<Cfg, PG_GI_FUSED, T>(a, stream);
+  }
+  if (variant == 4) {
+    using Cfg = TileCfg<T, 128, 192, 8, 2, 2, 3, 1>;
     if (a.gi_mode == PG_GI_ARRAY) return launch_fwd_cfg<Cfg, PG_GI_ARRAY, T>(a, stream);
     if (a.gi_mode == PG_GI_TABLE) return launch_fwd_cfg<Cfg, PG_GI_TABLE, T>(a, stream);
     return launch_fwd_cfg<Cfg, PG_GI_FUSED, T>(a, stream);
   }
   PG_REQUIRE(a.H % 8 == 0, "gru_fwd: hidden size must be a multiple of 8");
+  if (a.rows > 2048) {   // throughput regime (sampling): one K-group, two blocks per CU
+    if (a.gi_mode == PG_GI_ARRAY) return launch_fwd2<PG_GI_ARRAY, 1, 2, T>(a, stream);
+    if (a.gi_mode == PG_GI_TABLE) return launch_fwd2<PG_GI_TABLE, 1, 2, T>(a, stream);
+    return launch_fwd2<PG_GI_FUSED, 1, 2, T>(a, stream);
+  }
   if (a.gi_mode == PG_GI_ARRAY) return launch_fwd2<PG_GI_ARRAY, 2, 2, T>(a, stream);
   if (a.gi_mode == PG_GI_TABLE) return launch_fwd2<PG_GI_TABLE, 2, 2, T>(a, stream);
   return launch_fwd2<PG_GI_FUSED, 2, 2, T>(a, stream);

@@ -14,6 +14,6 @@ def run(which, rows, H, dt=_lib.PG_BF16, rep=300):
     s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
     s.record(); fn(rep); e.record(); e.synchronize()
     print("%s rows=%5d H=%4d: %7.2f us/launch" % ("fwd" if which == 0 else "bwd", rows, H, s.elapsed_time(e) / rep * 1e3))
-for rows in (64, 512, 1024):
+for rows in (64, 1024):
     run(0, rows, 512); run(1, rows, 512)
 
