@@ -1,0 +1,221 @@
+"""CPU tests: tokeniser / vocab bit-exactness vs the reference golden table, schedulers, host helpers, the C-ABI library's
+symbols (no compute calls), API surface (state_dict keys, parsers).  No GPU needed."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def vocab(golden_dir):
+    with open(os.path.join(golden_dir, "vocab.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def model():
+    from polygon_amd.vae.vae_model import VAE
+    return VAE()
+
+
+def test_vocab_bit_exact(vocab, model):
+    v = model.vocabulary
+    assert [v.i2c[i] for i in range(len(v))] == vocab["all_syms"]
+    assert (v.bos, v.eos, v.pad, v.unk) == (vocab["bos"], vocab["eos"], vocab["pad"], vocab["unk"])
+    assert (model.bos, model.eos, model.pad, model.unk) == (47, 48, 49, 50)
+    for s, ids in vocab["string2ids"]:
+        assert v.string2ids(s, add_bos=True, add_eos=True) == ids, s
+        assert model.string2tensor(s, device="cpu").tolist() == ids
+    for ids, s in vocab["ids2string"]:
+        if isinstance(s, dict):
+            with pytest.raises(IndexError):
+                v.ids2string(ids)
+        else:
+            assert v.ids2string(ids) == s
+            assert model.tensor2string(torch.tensor(ids, dtype=torch.long)) == s
+
+
+def test_encode_batch_equals_per_string(vocab, model):
+    v = model.vocabulary
+    strings = [s for s, _ in vocab["string2ids"]] + ["中文C", "CéN", "x" * 120]
+    tok, lens = v.encode_batch(strings)
+    for i, s in enumerate(strings):
+        ids = v.string2ids(s, True, True)
+        assert lens[i] == len(ids)
+        assert tok[i, :lens[i]].tolist() == ids, s
+        assert (tok[i, lens[i]:] == v.pad).all()
+
+
+def test_decode_batch_equals_ids2string(model):
+    v = model.vocabulary
+    rng = np.random.default_rng(0)
+    tok = rng.integers(0, 51, size=(64, 20)).astype(np.uint8)
+    tok[:, 0] = v.bos
+    ends = rng.integers(2, 21, size=64).astype(np.int32)
+    got = v.decode_batch(tok, ends)
+    for i in range(64):
+        assert got[i] == v.ids2string(tok[i, :ends[i]].tolist())
+
+
+def test_collate_sorts_stably_and_matches_reference(vocab, model):
+    data = list(vocab["collate_in"])
+    batch = model.get_collate_fn()(data)
+    assert data == vocab["collate_sorted"]                 # sorted in place, stable, descending
+    assert [t.tolist() for t in batch] == vocab["collate_ids"]
+    assert batch.lengths.tolist() == [len(x) for x in vocab["collate_ids"]]
+    sh = batch.shard(1, 2)
+    assert [t.tolist() for t in sh] == vocab["collate_ids"][1::2]
+
+
+def test_state_dict_and_param_layout(vocab, model):
+    assert list(model.state_dict().keys()) == vocab["state_dict_keys"]
+    assert [list(p.shape) for p in model.vae.parameters()] == vocab["param_shapes"]
+    assert sum(p.numel() for p in model.vae.parameters()) == vocab["n_params"]
+    assert torch.equal(model.x_emb.weight.data, torch.eye(51))
+
+
+def test_constructor_errors(model):
+    from polygon_amd.vae.vae_model import VAE
+    with pytest.raises(ValueError):
+        VAE(q_cell="lstm")
+    with pytest.raises(ValueError):
+        VAE(d_cell="lstm")
+    with pytest.raises(NotImplementedError):
+        VAE(q_bidir=True)
+    m = VAE(some_inert_flag=3)
+    assert m.some_inert_flag == 3
+
+
+def test_cpu_model_fails_loudly(model):
+    from polygon_amd._lib import PolygonHipError
+    with pytest.raises(PolygonHipError):
+        model(model.get_collate_fn()(["CCO", "C"]))
+
+
+def test_schedulers(vocab):
+    from polygon_amd.vae.vae_misc import CosineAnnealingLRWithRestart, KLAnnealer
+    n, s, w0, w1 = vocab["kl_annealer"]["args"]
+    kl = KLAnnealer(n, kl_start=s, kl_w_start=w0, kl_w_end=w1)
+    assert [kl(i) for i in range(10)] == pytest.approx(vocab["kl_annealer"]["values"], rel=1e-12)
+    with pytest.raises(ZeroDivisionError):
+        KLAnnealer(1, kl_start=1)
+    sg = vocab["sgdr"]
+    opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=sg["base_lr"])
+    sch = CosineAnnealingLRWithRestart(opt, lr_n_period=sg["lr_n_period"], lr_n_restarts=3, lr_n_mult=sg["lr_n_mult"],
+                                       lr_end=sg["lr_end"])
+    lrs = [opt.param_groups[0]["lr"]]
+    for _ in range(len(sg["lrs"]) - 1):
+        sch.step()
+        lrs.append(opt.param_groups[0]["lr"])
+    assert lrs == pytest.approx(sg["lrs"], rel=1e-12)
+
+
+def test_circular_buffer_mean_over_whole_array():
+    from polygon_amd.utils.moses_utils import CircularBuffer
+    b = CircularBuffer(4)
+    b.add(2.0)
+    b.add(4.0)
+    assert b.mean() == 1.5 and b.last() == 4.0
+
+
+def test_trainer_defaults_and_quirks(model):
+    from polygon_amd.vae.vae_trainer import VAETrainer
+    t = VAETrainer(model, n_batch=7, foo=1)
+    assert (t.n_epoch, t.clip_grad, t.kl_w_start, t.kl_start, t.lr_start, t.foo) == (10, 50, 0, 1, 0.0003, 1)
+    loader = t.get_dataloader(["C"] * 30, batch_size=3, shuffle=False)     # batch_size ignored, n_batch used
+    assert loader.batch_size == 7
+    assert VAETrainer(model, n_epoch=0)._n_epoch() == 60
+
+
+def test_cli_parsers_defaults():
+    from polygon_amd.run import get_parser
+    a = get_parser().parse_args(["train", "--train_data", "x", "--device", "cpu"])
+    assert (a.n_batch, a.d_dropout, a.kl_w_start, a.kl_start, a.save_frequency, a.n_epoch) == (512, 0.2, 1.0, 0, 20, 50)
+    g = get_parser().parse_args(["generate", "--model_path", "m", "--device", "cpu"])
+    assert (g.keep_top, g.mols_to_sample, g.optimize_batch_size, g.max_len, g.opti, g.kl_w_start) == (512, 1024, 256, 100, "gauss", 0)
+    from polygon_amd.utils.utils import torch_device
+    with pytest.raises(TypeError):
+        torch_device("gpu0")
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads and exports exactly what include/polygon_hip.h declares (no compute call here)."""
+    from polygon_amd import _lib
+    header = open(os.path.join(ROOT, "include", "polygon_hip.h")).read()
+    declared = sorted(set(re.findall(r"PG_API\s+[\w\s\*]+?\b(pg_\w+)\s*\(", header)))
+    assert len(declared) >= 14
+    lib = _lib.lib()
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.pg_version() == 1
+    assert lib.pg_last_error() is not None
+
+
+def test_library_host_side_argument_checks():
+    """Host-side validation paths of the C ABI run without a GPU: dims, dtype, unsorted lengths."""
+    from polygon_amd import _lib
+    from polygon_amd.vae.vae_model import _Dims
+    lib = _lib.lib()
+    lib.pg_param_count.restype = ctypes.c_long
+    lib.pg_shadow_bytes.restype = ctypes.c_size_t
+    lib.pg_train_workspace_bytes.restype = ctypes.c_size_t
+    d = _Dims(V=51, E=51, Hq=256, Dz=128, Hd=512, L=3, pad=49, bos=47, eos=48, unk=50)
+    assert lib.pg_param_count(ctypes.byref(d)) == 4614236
+    assert lib.pg_shadow_bytes(ctypes.byref(d), 1) > 0
+    assert lib.pg_train_workspace_bytes(ctypes.byref(d), 1, 1024, ctypes.c_long(51000)) > 0
+    bad = _Dims(V=200, E=51, Hq=256, Dz=128, Hd=512, L=3, pad=49, bos=47, eos=48, unk=50)
+    assert lib.pg_shadow_bytes(ctypes.byref(bad), 1) == 0
+    assert b"vocabulary" in lib.pg_last_error()
+    lens = np.array([3, 5], dtype=np.int32)       # not sorted: rejected before anything touches a device
+    st = lib.pg_encoder_fwd(ctypes.byref(d), 0, ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8),
+                            ctypes.c_size_t(1 << 40), 2, 5, ctypes.c_void_p(8), lens.ctypes.data_as(ctypes.c_void_p), None,
+                            None, 0, ctypes.c_void_p(8), None, None, None, None)
+    assert st != 0 and b"sorted" in lib.pg_last_error()
+
+
+def test_generator_loop_with_stub_scorer(monkeypatch, tmp_path):
+    """Control flow of optimise(): dedupe against `seen`, top-k by (score, smiles), 75/25 split, files written.
+    The model/trainer are stubbed (no GPU); canonicaliser = identity filter."""
+    from polygon_amd.vae import vae_generator as G
+
+    class FakeModel:
+        device = torch.device("cpu")
+        calls = 0
+
+        def sample(self, n, max_len=100):
+            FakeModel.calls += 1
+            return ["C" * (1 + (i + FakeModel.calls) % 7) for i in range(n)] + [""]
+
+    fits = []
+
+    class FakeTrainer:
+        def __init__(self, model, **kw):
+            self.model = model
+            self.kw = kw
+
+        def fit(self, train, val=None, n_epoch=None, batch_size=None, save_frequency=None):
+            fits.append((len(train), 0 if val is None else len(val), n_epoch, batch_size))
+
+    monkeypatch.setattr(G, "VAETrainer", FakeTrainer)
+    monkeypatch.setattr(G, "save_model", lambda m, p: open(p, "w").close())
+
+    class Obj:
+        def score_list(self, sm):
+            return [float(len(s)) for s in sm]
+
+    gen = G.SmilesVaeMoleculeGenerator(FakeModel(), 100, "cpu", str(tmp_path), canonicalizer=lambda s, include_stereocenters=True: [x for x in s if x])
+    assert gen.trainer.kw["kl_w_start"] == 1 and gen.trainer.kw["model_save"] is None
+    res = gen.optimise(Obj(), [], keep_top=4, n_epochs=3, mols_to_sample=16, optimize_n_epochs=2, optimize_batch_size=512,
+                       pretrain_n_epochs=1, save_frequency=2, save_payloads=True)
+    assert [r.smiles for r in res[:2]] == ["CCCCCCC", "CCCCCC"]
+    assert res == sorted(res, reverse=True)
+    assert fits[0] == (3, 1, 2, 3)
+    assert os.path.exists(tmp_path / "GDM_2.pt") and not os.path.exists(tmp_path / "GDM_1.pt")
+    assert os.path.exists(tmp_path / "GDM_ongoing_top_scoring_molecules.txt") and os.path.exists(tmp_path / "GDM_1_payload.txt")
+    assert G.OptResult("a", 1.0) < G.OptResult("b", 1.0) < G.OptResult("a", 2.0)
