@@ -47,25 +47,30 @@ def hip_events_ms(fn, stream, iters):
 
 
 def roofline_gate_gemm(dtype, B, H):
-    """Dominant kernel class: the gate GEMM of one GRU step ([B,H] x [H,3H], the MFMA tile engine).  Measured live through
-    the pg_gemm_nt hook (same mma_mainloop_nt + epilogue store as the recurrent step kernels) on torch's current stream."""
-    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    """Dominant kernel (rocprof: profiles/): the BPTT step kernel gru_bwd2_kernel = gate-gradient GEMM
+    [B,3H]x[3H,H] on MFMA + fused gate-gradient epilogue.  Timed live with HIP events on the stream it is launched on
+    (a C-side loop of launches through pg_bench_gru, rows = B).  Algorithmic flop per launch = 2*B*3H*H."""
     code = _lib.PG_BF16 if dtype == "bf16" else _lib.PG_F32
-    A = torch.randn(B, H, device="cuda").to(tdt)
-    W = (torch.randn(3 * H, H, device="cuda") / H ** 0.5).to(tdt)
-    C = torch.empty(B, 3 * H, device="cuda")
     L = _lib.lib()
+    nbytes = 80 * B * H + 16 * H * H + (1 << 20)
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
     st = torch.cuda.current_stream()
+    reps = 200
 
-    def fn():
-        _lib.check(L.pg_gemm_nt(code, _lib.ptr(A), ctypes.c_long(H), _lib.ptr(W), ctypes.c_long(H), B, 3 * H, H, None,
-                                _lib.ptr(C), None, ctypes.c_long(3 * H), 0, ctypes.c_float(1.0),
-                                ctypes.c_void_p(st.cuda_stream)))
-    ms = hip_events_ms(fn, st, 200)
+    def run(which):
+        def fn():
+            _lib.check(L.pg_bench_gru(code, which, B, H, _lib.ptr(ws), ctypes.c_size_t(nbytes), reps,
+                                      ctypes.c_void_p(st.cuda_stream)))
+        return hip_events_ms(fn, st, 3) / reps
+    ms_bwd, ms_fwd = run(1), run(0)
     flops = 2.0 * B * H * 3 * H
-    ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_nt_kernel (GRU gate GEMM [%d,%d]x[%d,%d])" % (B, H, H, 3 * H), "achieved": ach,
-            "peak": PEAK[dtype], "unit": "TFLOP/s", "frac": ach / PEAK[dtype], "traffic": None, "avg_launch_us": ms * 1e3}
+    ach = flops / (ms_bwd * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gru_bwd2_kernel (BPTT step: dGH[%d,%d] x W_hh[%d,%d] + gate-gradient epilogue)" % (B, 3 * H, 3 * H, H),
+            "achieved": ach, "peak": PEAK[dtype], "unit": "TFLOP/s", "frac": ach / PEAK[dtype], "traffic": None,
+            "avg_launch_us": ms_bwd * 1e3, "flop_per_launch": flops,
+            "fwd_step_kernel": {"kernel": "gru_fwd2_kernel", "avg_launch_us": ms_fwd * 1e3,
+                                "achieved": flops / (ms_fwd * 1e-3) / 1e12},
+            "note": "step kernels are latency-bound (launch floor ~2.6 us + operand fetch + short K loop), see DESIGN.md 3"}
 
 
 def cpu_baseline(n_strings=192):
