@@ -3,7 +3,7 @@
 #pragma once
 #include "pg_common.h"
 
-enum { PG_GI_ARRAY = 0, PG_GI_TABLE = 1, PG_GI_FUSED = 2 };
+enum { PG_GI_ARRAY = 0, PG_GI_TABLE = 1, PG_GI_FUSED = 2, PG_GI_DYN = 3 /* kernel-internal: read a.gi_mode at run time */ };
 
 template <typename T> struct GruFwdArgs {
   int rows = 0, H = 0;
@@ -47,8 +47,27 @@ template <typename T> struct GruBwdArgs {
   int final_step = 0;            // 1: only dh0 (+)= acc + dhz_in for rows_out rows
   float* dh0 = nullptr;
   int dh0_accumulate = 0;
+  // wavefront mode: the gradient from the layer above is computed here instead of arriving in `dout`:
+  //   dout_t = dropmask(layer, t) * (dGI_up[rows_out, 3H] . WihT_up[H, 3H]^T)
+  const T* dGI_up = nullptr;
+  const T* WihT_up = nullptr;
+  float p_drop = 0.0f;
+  unsigned long long seed = 0;
+  int layer = 0, t = 0, b_mul = 1, b_add = 0;
   int dbg = 0;
 };
+
+// One launch = one anti-diagonal of the (layer, t) grid of the decoder: up to PG_MAX_LAYERS independent cells.
+template <typename T> struct GruFwdDiag {
+  int n = 0;
+  GruFwdArgs<T> a[8];
+};
+template <typename T> struct GruBwdDiag {
+  int n = 0;
+  GruBwdArgs<T> a[8];
+};
+template <typename T> int launch_gru_fwd_diag(const GruFwdDiag<T>& d, hipStream_t stream);
+template <typename T> int launch_gru_bwd_diag(const GruBwdDiag<T>& d, hipStream_t stream);
 
 template <typename T> int launch_gru_fwd(const GruFwdArgs<T>& a, hipStream_t stream);
 template <typename T> int launch_gru_bwd(const GruBwdArgs<T>& a, hipStream_t stream);

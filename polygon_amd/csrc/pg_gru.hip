@@ -248,15 +248,15 @@ __device__ __forceinline__ void v2_exchange(f32x16 (&acc)[Cfg::TM][NACC], float*
   }
 }
 
-template <typename T, int MODE, int G, int D>
-__global__ __launch_bounds__(256 * G) void gru_fwd2_kernel(GruFwdArgs<T> a) {
+template <typename T, int MODE_T, int G, int D>
+__device__ __forceinline__ void gru_fwd2_body(const GruFwdArgs<T>& a, int bx, int by, char* smem) {
   using Cfg = TileCfg<T, V2_BM, 3 * V2_BH, 8, 2, 2, 3, D>;
   static_assert(Cfg::TM == 1 && Cfg::TU == 1, "v2 geometry");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NACC = MODE == PG_GI_FUSED ? 4 : 3;
+  constexpr int NACC = (MODE_T == PG_GI_FUSED || MODE_T == PG_GI_DYN) ? 4 : 3;
   constexpr int NTH = 256 * G;
+  const int MODE = MODE_T == PG_GI_DYN ? a.gi_mode : MODE_T;   // block-uniform
   const int H = a.H;
-  const int j0 = blockIdx.x * V2_BH, m0 = blockIdx.y * V2_BM;
+  const int j0 = bx * V2_BH, m0 = by * V2_BM;
   const int tid = threadIdx.x, group = tid >> 8, gtid = tid & 255;
   // ---- epilogue assignment + input prefetch: chunk c covers row c/8, columns 8*(c%8)..+7 of the 64x64 tile
   constexpr int CH = (V2_BM * V2_BH / 8 + NTH - 1) / NTH;
@@ -301,11 +301,13 @@ __global__ __launch_bounds__(256 * G) void gru_fwd2_kernel(GruFwdArgs<T> a) {
     GateRowSrc<T> bs{a.Whh, H, H, j0, V2_BH};
     mma_mainloop_nt<Cfg, NACC, 2>(acc, as, bs, H, gsm, gtid, group * nkg, nkg);
   }
-  if (MODE == PG_GI_FUSED) {
-    const int nkg = ((a.Kx + Cfg::BK - 1) / Cfg::BK + G - 1) / G;
-    RowSrc<T> as{a.x, a.Kx, m0, a.rows};
-    GateRowSrc<T> bs{a.Wih, a.Kx, H, j0, V2_BH};
-    mma_mainloop_nt<Cfg, NACC, 3>(acc, as, bs, a.Kx, gsm, gtid, group * nkg, nkg);
+  if constexpr (NACC == 4) {
+    if (MODE == PG_GI_FUSED) {
+      const int nkg = ((a.Kx + Cfg::BK - 1) / Cfg::BK + G - 1) / G;
+      RowSrc<T> as{a.x, a.Kx, m0, a.rows};
+      GateRowSrc<T> bs{a.Wih, a.Kx, H, j0, V2_BH};
+      mma_mainloop_nt<Cfg, NACC, 3>(acc, as, bs, a.Kx, gsm, gtid, group * nkg, nkg);
+    }
   }
   float* xt = reinterpret_cast<float*>(smem);
   if (a.dbg & 2) { if (acc[0][0][0] == 123.456f || gr[0][0] == 77.7f) a.h32[0] = 1.0f; return; }
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(256 * G) void gru_fwd2_kernel(GruFwdArgs<T> a) {
     Vec8<float>::load(xt + (0 * V2_BM + row) * V2_LD + col, ar);
     Vec8<float>::load(xt + (1 * V2_BM + row) * V2_LD + col, az);
     Vec8<float>::load(xt + (2 * V2_BM + row) * V2_LD + col, ahn);
-    if (MODE == PG_GI_FUSED) Vec8<float>::load(xt + (3 * V2_BM + row) * V2_LD + col, ain);
+    if (NACC == 4) Vec8<float>::load(xt + (3 * V2_BM + row) * V2_LD + col, ain);
     Vec8<float>::load(a.bhn + j, bhn);
     float h[8], r[8], z[8], n[8], hn[8];
 #pragma unroll
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256 * G) void gru_fwd2_kernel(GruFwdArgs<T> a) {
       r[i] = sigmoidf_(gr[c][i] + ar[i]);
       z[i] = sigmoidf_(gz[c][i] + az[i]);
       hn[i] = ahn[i] + bhn[i];
-      const float gnn = MODE == PG_GI_FUSED ? gn[c][i] + ain[i] : gn[c][i];
+      const float gnn = (NACC == 4 && MODE == PG_GI_FUSED) ? gn[c][i] + ain[i] : gn[c][i];
       n[i] = tanhf_(gnn + r[i] * hn[i]);
       h[i] = (1.0f - z[i]) * n[i] + z[i] * hp[c][i];
     }
@@ -352,13 +354,26 @@ __global__ __launch_bounds__(256 * G) void gru_fwd2_kernel(GruFwdArgs<T> a) {
   }
 }
 
-template <typename T, int G, int D>
-__global__ __launch_bounds__(256 * G) void gru_bwd2_kernel(GruBwdArgs<T> a) {
-  using Cfg = TileCfg<T, V2_BM, V2_BH, 8, 2, 2, 1, D>;
+template <typename T, int MODE, int G, int D>
+__global__ __launch_bounds__(256 * G) void gru_fwd2_kernel(GruFwdArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  gru_fwd2_body<T, MODE, G, D>(a, blockIdx.x, blockIdx.y, smem);
+}
+template <typename T, int G, int D>
+__global__ __launch_bounds__(256 * G) void gru_fwd2_diag_kernel(GruFwdDiag<T> d) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const GruFwdArgs<T>& a = d.a[blockIdx.z];
+  if ((int)blockIdx.y * V2_BM >= a.rows) return;   // block-uniform: this cell has fewer rows than the widest one
+  gru_fwd2_body<T, PG_GI_DYN, G, D>(a, blockIdx.x, blockIdx.y, smem);
+}
+
+template <typename T, int G, int D, bool UP>
+__device__ __forceinline__ void gru_bwd2_body(const GruBwdArgs<T>& a, int bx, int by, char* smem) {
+  using Cfg = TileCfg<T, V2_BM, V2_BH, 8, 2, 2, 1, D>;
   constexpr int NTH = 256 * G;
+  constexpr int NACC = UP ? 2 : 1;
   const int H = a.H;
-  const int j0 = blockIdx.x * V2_BH, m0 = blockIdx.y * V2_BM;
+  const int j0 = bx * V2_BH, m0 = by * V2_BM;
   const int tid = threadIdx.x, group = tid >> 8, gtid = tid & 255;
   constexpr int CH = (V2_BM * V2_BH / 8 + NTH - 1) / NTH;
   float dh[CH][8], r[CH][8], z[CH][8], n[CH][8], hn[CH][8], hp[CH][8];
@@ -387,20 +402,28 @@ __global__ __launch_bounds__(256 * G) void gru_bwd2_kernel(GruBwdArgs<T> a) {
       }
     }
   }
-  f32x16 acc[1][1];
+  f32x16 acc[1][NACC];
   {
     const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    acc[0][0] = zacc;
+#pragma unroll
+    for (int s = 0; s < NACC; ++s) acc[0][s] = zacc;
   }
+  const int nkg = ((3 * H + Cfg::BK - 1) / Cfg::BK + G - 1) / G;
   if (a.rows_in > 0 && m0 < a.rows_in && !(a.dbg & 1)) {   // block-uniform
-    const int nkg = ((3 * H + Cfg::BK - 1) / Cfg::BK + G - 1) / G;
     RowSrc<T> as{a.dGH_in, 3L * H, m0, a.rows_in};
     RowSrc<T> bs{a.WhhT, 3L * H, j0, H};
-    mma_mainloop_nt<Cfg, 1, 0>(acc, as, bs, 3 * H, smem + group * Cfg::SMEM_BYTES, gtid, group * nkg, nkg);
+    mma_mainloop_nt<Cfg, NACC, 0>(acc, as, bs, 3 * H, smem + group * Cfg::SMEM_BYTES, gtid, group * nkg, nkg);
+  }
+  if constexpr (UP) {
+    if (a.dGI_up && !a.final_step) {   // gradient arriving from the layer above, same time step
+      RowSrc<T> as{a.dGI_up, 3L * H, m0, a.rows_out};
+      RowSrc<T> bs{a.WihT_up, 3L * H, j0, H};
+      mma_mainloop_nt<Cfg, NACC, 1>(acc, as, bs, 3 * H, smem + group * Cfg::SMEM_BYTES, gtid, group * nkg, nkg);
+    }
   }
   float* xt = reinterpret_cast<float*>(smem);
   if (a.dbg & 2) { if (acc[0][0][0] == 123.456f || dh[0][0] == 77.7f) a.dhz_out[0] = 1.0f; return; }
-  v2_exchange<Cfg, 1>(acc, xt, gtid, group, G);
+  v2_exchange<Cfg, NACC>(acc, xt, gtid, group, G);
   if (a.dbg & 8) { if (xt[tid] == 123.456f) a.dhz_out[0] = 1.0f; return; }
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
@@ -414,6 +437,20 @@ __global__ __launch_bounds__(256 * G) void gru_bwd2_kernel(GruBwdArgs<T> a) {
     if (b < a.rows_in) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) dh[c][i] += ac[i];
+    }
+    if constexpr (UP) {
+      if (a.dGI_up && !a.final_step) {
+        float au[8];
+        Vec8<float>::load(xt + (V2_BM + row) * V2_LD + col, au);
+        const float inv_keep = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float m = a.p_drop > 0.0f
+                              ? dropout_scale(a.seed, a.layer, a.t, b * a.b_mul + a.b_add, j + i, a.p_drop, inv_keep)
+                              : 1.0f;
+          dh[c][i] += m * au[i];
+        }
+      }
     }
     if (a.final_step) {
       Vec8<float>::store(a.dh0 + o, dh[c]);
@@ -433,6 +470,19 @@ __global__ __launch_bounds__(256 * G) void gru_bwd2_kernel(GruBwdArgs<T> a) {
     Vec8<T>::store(a.dGH + og, drp); Vec8<T>::store(a.dGH + og + H, dzp); Vec8<T>::store(a.dGH + og + 2 * H, dnr);
     Vec8<float>::store(a.dhz_out + o, dhz);
   }
+}
+
+template <typename T, int G, int D>
+__global__ __launch_bounds__(256 * G) void gru_bwd2_kernel(GruBwdArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gru_bwd2_body<T, G, D, false>(a, blockIdx.x, blockIdx.y, smem);
+}
+template <typename T, int G, int D>
+__global__ __launch_bounds__(256 * G) void gru_bwd2_diag_kernel(GruBwdDiag<T> d) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const GruBwdArgs<T>& a = d.a[blockIdx.z];
+  if ((int)blockIdx.y * V2_BM >= a.rows_out) return;
+  gru_bwd2_body<T, G, D, true>(a, blockIdx.x, blockIdx.y, smem);
 }
 
 template <int MODE, int G, int D, typename T> static int launch_fwd2(const GruFwdArgs<T>& a, hipStream_t stream) {
@@ -513,6 +563,46 @@ template <typename T> int launch_gru_bwd(const GruBwdArgs<T>& a, hipStream_t str
   PG_CHECK_LAUNCH();
   return PG_OK;
 }
+
+template <typename T> int launch_gru_fwd_diag(const GruFwdDiag<T>& d, hipStream_t stream) {
+  if (d.n <= 0) return PG_OK;
+  constexpr int G = 2, D = 2;
+  using Cfg = TileCfg<T, V2_BM, 3 * V2_BH, 8, 2, 2, 3, D>;
+  constexpr size_t smem = (size_t)G * Cfg::SMEM_BYTES;
+  int rows = 0, H = d.a[0].H;
+  for (int i = 0; i < d.n; ++i) {
+    PG_REQUIRE(d.a[i].H == H && H % 8 == 0, "gru_fwd_diag: all cells must share one hidden size (multiple of 8)");
+    PG_REQUIRE(d.a[i].gi_mode != PG_GI_FUSED || d.a[i].Kx % (16 / (int)sizeof(T)) == 0, "gru_fwd_diag: bad fused input width");
+    rows = rows > d.a[i].rows ? rows : d.a[i].rows;
+  }
+  if (rows <= 0) return PG_OK;
+  dim3 grid(cdiv(H, V2_BH), cdiv(rows, V2_BM), d.n);
+  PG_LAUNCH_BIG_SMEM((gru_fwd2_diag_kernel<T, G, D>), grid, dim3(256 * G), smem, stream, d);
+  PG_CHECK_LAUNCH();
+  return PG_OK;
+}
+template <typename T> int launch_gru_bwd_diag(const GruBwdDiag<T>& d, hipStream_t stream) {
+  if (d.n <= 0) return PG_OK;
+  constexpr int G = 4, D = 2;
+  using Cfg = TileCfg<T, V2_BM, V2_BH, 8, 2, 2, 1, D>;
+  constexpr size_t smem = (size_t)G * Cfg::SMEM_BYTES;
+  static_assert(smem >= 2 * V2_BM * V2_LD * 4, "exchange tiles must fit the staging LDS");
+  int rows = 0, H = d.a[0].H;
+  for (int i = 0; i < d.n; ++i) {
+    PG_REQUIRE(d.a[i].H == H && H % 8 == 0, "gru_bwd_diag: all cells must share one hidden size (multiple of 8)");
+    PG_REQUIRE(d.a[i].rows_in <= d.a[i].rows_out, "gru_bwd_diag: rows_in > rows_out (batch must be sorted by length)");
+    rows = rows > d.a[i].rows_out ? rows : d.a[i].rows_out;
+  }
+  if (rows <= 0) return PG_OK;
+  dim3 grid(cdiv(H, V2_BH), cdiv(rows, V2_BM), d.n);
+  PG_LAUNCH_BIG_SMEM((gru_bwd2_diag_kernel<T, G, D>), grid, dim3(256 * G), smem, stream, d);
+  PG_CHECK_LAUNCH();
+  return PG_OK;
+}
+template int launch_gru_fwd_diag<float>(const GruFwdDiag<float>&, hipStream_t);
+template int launch_gru_fwd_diag<bf16_t>(const GruFwdDiag<bf16_t>&, hipStream_t);
+template int launch_gru_bwd_diag<float>(const GruBwdDiag<float>&, hipStream_t);
+template int launch_gru_bwd_diag<bf16_t>(const GruBwdDiag<bf16_t>&, hipStream_t);
 
 template int launch_gru_fwd<float>(const GruFwdArgs<float>&, hipStream_t);
 template int launch_gru_fwd<bf16_t>(const GruFwdArgs<bf16_t>&, hipStream_t);

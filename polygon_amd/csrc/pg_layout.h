@@ -128,6 +128,7 @@ struct TrainWs {
   size_t d_zop, d_zproj, d_h0_32, d_h0_op, d_carry[PG_MAX_LAYERS], d_hseq[PG_MAX_LAYERS], d_hdrop[PG_MAX_LAYERS];
   size_t d_sv[PG_MAX_LAYERS][5], d_gi, d_logits, d_dlogits;
   // backward
+  size_t b_dGI_l[PG_MAX_LAYERS], b_dGH_l[PG_MAX_LAYERS], b_dhz_l[PG_MAX_LAYERS][2];
   size_t b_dout, b_dGI, b_dGH, b_dhz[2], b_dh0, b_dh0_op, b_dzproj, b_dzproj_op, b_onehot, b_dT, b_dq, b_dq_op, b_dhfin;
   size_t total;
 };
@@ -158,6 +159,10 @@ static inline TrainWs train_ws_layout(const pg_dims* d, int dtype, long B, long 
   w.b_dout = take(Nd * Hd * 4);
   w.b_dGI = take(Nm * 3 * Hm * es); w.b_dGH = take(Nm * 3 * Hm * es);
   w.b_dhz[0] = take(B * Hm * 4); w.b_dhz[1] = take(B * Hm * 4);
+  for (int l = 0; l < d->L; ++l) {   // the decoder BPTT runs as a wavefront over layers: every layer keeps its own buffers
+    w.b_dGI_l[l] = take(Nd * 3 * Hd * es); w.b_dGH_l[l] = take(Nd * 3 * Hd * es);
+    w.b_dhz_l[l][0] = take(B * Hd * 4); w.b_dhz_l[l][1] = take(B * Hd * 4);
+  }
   w.b_dh0 = take(B * Hd * 4); w.b_dh0_op = take(B * Hd * es);
   w.b_dzproj = take(B * 3 * Hd * 4); w.b_dzproj_op = take(B * 3 * Hd * es);
   w.b_onehot = take(Nm * Vp * es); w.b_dT = take(Vp * 3 * Hm * 4);

@@ -234,21 +234,23 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
     PG_TRY(launch_gemm_nt<T>(z_op, Dz, at<T>(shadow, so.lat_w), Dz, B, Hd, Dz, e, st));
   }
   const bool drop = p_drop > 0.0f;
-  for (int l = 0; l < L; ++l) {
-    float* carry = at<float>(ws, w.d_carry[l]);
-    PG_CHECK_HIP(hipMemcpyAsync(carry, at<float>(ws, w.d_h0_32), (size_t)B * Hd * 4, hipMemcpyDeviceToDevice, st));
-    T* hseq = at<T>(ws, w.d_hseq[l]);
-    if (l > 0) {  // batched input projection of the whole layer (non-recurrent)
-      const T* X = drop ? at<T>(ws, w.d_hdrop[l - 1]) : at<T>(ws, w.d_hseq[l - 1]);
-      GemmEpi<T> e;
-      e.bias = at<float>(shadow, so.bias_gi[l]); e.C32 = at<float>(ws, w.d_gi); e.ldc = 3 * Hd;
-      PG_TRY(launch_gemm_nt<T>(X, Hd, at<T>(shadow, so.wih[l]), Hd, (int)Nd, 3 * Hd, Hd, e, st));
-    }
-    for (int t = 0; t < sd.T; ++t) {
-      GruFwdArgs<T> a;
+  for (int l = 0; l < L; ++l)
+    PG_CHECK_HIP(hipMemcpyAsync(at<float>(ws, w.d_carry[l]), at<float>(ws, w.d_h0_32), (size_t)B * Hd * 4,
+                                hipMemcpyDeviceToDevice, st));
+  // Wavefront over the (layer, t) grid: cell (l, t) needs (l, t-1) and (l-1, t), so all cells of one anti-diagonal
+  // are independent and run in ONE launch; layers >= 1 take their input projection fused (x = output of the layer
+  // below at the same step).  T + L - 1 sequential launches instead of T * L.
+  for (int dgi = 0; dgi < sd.T + L - 1; ++dgi) {
+    GruFwdDiag<T> dg;
+    for (int l = 0; l < L; ++l) {
+      const int t = dgi - l;
+      if (t < 0 || t >= sd.T) continue;
+      GruFwdArgs<T>& a = dg.a[dg.n++];
+      T* hseq = at<T>(ws, w.d_hseq[l]);
+      const long o = (long)sd.off[t] * Hd;
       a.rows = sched_B(sd, t); a.H = Hd;
       a.hprev_op = t == 0 ? at<T>(ws, w.d_h0_op) : hseq + (long)sd.off[t - 1] * Hd;
-      a.hprev32 = carry;
+      a.hprev32 = at<float>(ws, w.d_carry[l]);
       a.Whh = at<T>(shadow, so.whh[l]);
       a.bhn = params + po.dec_bhh[l] + 2 * Hd;
       if (l == 0) {
@@ -257,12 +259,14 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
         a.tok = at<int>(ws, w.dec_tok) + sd.off[t];
         a.zproj = at<float>(ws, w.d_zproj);
       } else {
-        a.gi_mode = PG_GI_ARRAY;
-        a.gi = at<float>(ws, w.d_gi) + (long)sd.off[t] * 3 * Hd;
+        a.gi_mode = PG_GI_FUSED;
+        a.x = (drop ? at<T>(ws, w.d_hdrop[l - 1]) : at<T>(ws, w.d_hseq[l - 1])) + o;
+        a.Kx = Hd;
+        a.Wih = at<T>(shadow, so.wih[l]);
+        a.bias_gi = at<float>(shadow, so.bias_gi[l]);
       }
-      const long o = (long)sd.off[t] * Hd;
       a.h_op = hseq + o;
-      a.h32 = carry;
+      a.h32 = at<float>(ws, w.d_carry[l]);
       if (save) {
         a.sv_r = at<T>(ws, w.d_sv[l][0]) + o; a.sv_z = at<T>(ws, w.d_sv[l][1]) + o; a.sv_n = at<T>(ws, w.d_sv[l][2]) + o;
         a.sv_hn = at<T>(ws, w.d_sv[l][3]) + o; a.sv_hprev = at<T>(ws, w.d_sv[l][4]) + o;
@@ -271,8 +275,8 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
         a.h_drop = at<T>(ws, w.d_hdrop[l]) + o;
         a.p_drop = p_drop; a.seed = seed; a.layer = l; a.t = t; a.b_mul = b_mul; a.b_add = b_add;
       }
-      PG_TRY(launch_gru_fwd<T>(a, st));
     }
+    PG_TRY(launch_gru_fwd_diag<T>(dg, st));
   }
   {  // vocab projection
     GemmEpi<T> e;
@@ -332,34 +336,49 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
     e.C32 = dout; e.ldc = Hd; e.alpha_dev = s_ce;
     PG_TRY(launch_gemm_nt<T>(dlog, Vp, at<T>(shadow, so.fc_wT), Vp, (int)Nd, Hd, Vp, e, st));
   }
-  T* dGI = at<T>(ws, w.b_dGI);
-  T* dGH = at<T>(ws, w.b_dGH);
   float* dh0 = at<float>(ws, w.b_dh0);
   const bool drop = p_drop > 0.0f;
-  for (int l = L - 1; l >= 0; --l) {
-    for (int t = sd.T - 1; t >= -1; --t) {
-      GruBwdArgs<T> a;
+  // BPTT as a wavefront: cell (l, t) needs (l, t+1) and (l+1, t); the gradient coming down from layer l+1 is
+  // computed inside the cell (dGI_{l+1,t} . W_ih_{l+1}, through layer l's dropout mask), so no per-layer dX GEMM.
+  for (int dgi = 0; dgi < sd.T + L; ++dgi) {
+    GruBwdDiag<T> dg;
+    for (int l = L - 1; l >= 0; --l) {
+      const int t = sd.T - 1 - (dgi - (L - 1 - l));
+      if (t < -1 || t > sd.T - 1) continue;
+      GruBwdArgs<T>& a = dg.a[dg.n++];
+      T* dGI = at<T>(ws, w.b_dGI_l[l]);
+      T* dGH = at<T>(ws, w.b_dGH_l[l]);
       a.H = Hd;
       a.rows_in = (t + 1 < sd.T) ? sched_B(sd, t + 1) : 0;
       a.dGH_in = dGH + (long)sd.off[t + 1 < sd.T ? t + 1 : 0] * 3 * Hd;
       a.WhhT = at<T>(shadow, so.whhT[l]);
-      a.dhz_in = at<float>(ws, w.b_dhz[(t + 1) & 1]);
+      a.dhz_in = at<float>(ws, w.b_dhz_l[l][(t + 1) & 1]);
       if (t >= 0) {
         const long o = (long)sd.off[t] * Hd;
         a.rows_out = sched_B(sd, t);
-        a.dout = dout + o;
+        if (l == L - 1) {
+          a.dout = dout + o;
+        } else {
+          a.dGI_up = at<T>(ws, w.b_dGI_l[l + 1]) + o * 3;
+          a.WihT_up = at<T>(shadow, so.wihT[l + 1]);
+          if (drop) { a.p_drop = p_drop; a.seed = seed; a.layer = l; a.t = t; a.b_mul = b_mul; a.b_add = b_add; }
+        }
         a.sv_r = at<T>(ws, w.d_sv[l][0]) + o; a.sv_z = at<T>(ws, w.d_sv[l][1]) + o; a.sv_n = at<T>(ws, w.d_sv[l][2]) + o;
         a.sv_hn = at<T>(ws, w.d_sv[l][3]) + o; a.sv_hprev = at<T>(ws, w.d_sv[l][4]) + o;
         a.dGI = dGI + o * 3; a.dGH = dGH + o * 3;
-        a.dhz_out = at<float>(ws, w.b_dhz[t & 1]);
-      } else {  // gradient of h0 (shared by all layers)
+        a.dhz_out = at<float>(ws, w.b_dhz_l[l][t & 1]);
+      } else {  // gradient of h0 (shared by all layers); layer L-1 gets there first
         a.rows_out = a.rows_in;
         a.final_step = 1;
         a.dh0 = dh0;
         a.dh0_accumulate = (l != L - 1);
       }
-      PG_TRY(launch_gru_bwd<T>(a, st));
     }
+    PG_TRY(launch_gru_bwd_diag<T>(dg, st));
+  }
+  for (int l = L - 1; l >= 0; --l) {
+    T* dGI = at<T>(ws, w.b_dGI_l[l]);
+    T* dGH = at<T>(ws, w.b_dGH_l[l]);
     // weight / bias gradients of the layer (batched over all packed rows)
     PG_TRY(launch_gemm_tn<T>(dGH, 3 * Hd, at<T>(ws, w.d_sv[l][4]), Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_whh[l], Hd, 1.0f,
                              nullptr, st));
@@ -368,13 +387,6 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
     if (l > 0) {
       const T* X = drop ? at<T>(ws, w.d_hdrop[l - 1]) : at<T>(ws, w.d_hseq[l - 1]);
       PG_TRY(launch_gemm_tn<T>(dGI, 3 * Hd, X, Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_wih[l], Hd, 1.0f, nullptr, st));
-      GemmEpi<T> e;  // gradient wrt the layer below's outputs (through its dropout mask)
-      e.C32 = dout; e.ldc = Hd;
-      if (drop) {
-        e.p_drop = p_drop; e.seed = seed; e.layer = l - 1; e.row_t = at<int>(ws, w.dec_t); e.row_b = at<int>(ws, w.dec_b);
-        e.b_mul = b_mul; e.b_add = b_add;
-      }
-      PG_TRY(launch_gemm_nt<T>(dGI, 3 * Hd, at<T>(shadow, so.wihT[l]), 3 * Hd, (int)Nd, Hd, 3 * Hd, e, st));
     } else {
       // layer 0 input = [x_emb[token] ; z]: token half through the gather table, z half per sequence
       T* oh = at<T>(ws, w.b_onehot);
