@@ -295,18 +295,18 @@ __device__ __forceinline__ void gru_fwd2_body(const GruFwdArgs<T>& a, int bx, in
     for (int s = 0; s < NACC; ++s) acc[0][s] = zacc;
   }
   char* gsm = smem + group * Cfg::SMEM_BYTES;
-  if (a.hprev_op && !(a.dbg & 1)) {
-    const int nkg = ((H + Cfg::BK - 1) / Cfg::BK + G - 1) / G;
-    RowSrc<T> as{a.hprev_op, H, m0, a.rows};
-    GateRowSrc<T> bs{a.Whh, H, H, j0, V2_BH};
-    mma_mainloop_nt<Cfg, NACC, 2>(acc, as, bs, H, gsm, gtid, group * nkg, nkg);
-  }
-  if constexpr (NACC == 4) {
-    if (MODE == PG_GI_FUSED) {
-      const int nkg = ((a.Kx + Cfg::BK - 1) / Cfg::BK + G - 1) / G;
-      RowSrc<T> as{a.x, a.Kx, m0, a.rows};
-      GateRowSrc<T> bs{a.Wih, a.Kx, H, j0, V2_BH};
-      mma_mainloop_nt<Cfg, NACC, 3>(acc, as, bs, a.Kx, gsm, gtid, group * nkg, nkg);
+  {
+    // one pipelined K loop over [h_{t-1} | x] against [W_hh | W_ih]
+    const int K1 = (a.hprev_op && !(a.dbg & 1)) ? H : 0;
+    const int K2 = (NACC == 4 && MODE == PG_GI_FUSED) ? a.Kx : 0;
+    const int nkt = (K1 + Cfg::BK - 1) / Cfg::BK + (K2 + Cfg::BK - 1) / Cfg::BK;
+    const int nkg = (nkt + G - 1) / G;
+    if (nkt > 0) {
+      RowSrc<T> a1{K1 > 0 ? a.hprev_op : a.x, H, m0, a.rows};
+      GateRowSrc<T> b1{K1 > 0 ? a.Whh : a.Wih, H, H, j0, V2_BH};
+      RowSrc<T> a2{a.x, a.Kx, m0, a.rows};
+      GateRowSrc<T> b2{a.Wih, a.Kx, H, j0, V2_BH};
+      mma_mainloop_nt2<Cfg, NACC, 2, NACC == 4 ? 3 : 2>(acc, a1, b1, K1, a2, b2, K2, gsm, gtid, group * nkg, nkg);
     }
   }
   float* xt = reinterpret_cast<float*>(smem);
@@ -367,8 +367,9 @@ __global__ __launch_bounds__(256 * G) void gru_fwd2_diag_kernel(GruFwdDiag<T> d)
   gru_fwd2_body<T, PG_GI_DYN, G, D>(a, blockIdx.x, blockIdx.y, smem);
 }
 
-template <typename T, int G, int D, bool UP>
+template <typename T, int G, int D, bool UP, bool PRE = true>
 __device__ __forceinline__ void gru_bwd2_body(const GruBwdArgs<T>& a, int bx, int by, char* smem) {
+  // PRE: fetch the epilogue inputs before the K loop (latency hidden, +48 VGPRs) or after it (register-tight builds)
   using Cfg = TileCfg<T, V2_BM, V2_BH, 8, 2, 2, 1, D>;
   constexpr int NTH = 256 * G;
   constexpr int NACC = UP ? 2 : 1;
@@ -377,6 +378,7 @@ __device__ __forceinline__ void gru_bwd2_body(const GruBwdArgs<T>& a, int bx, in
   const int tid = threadIdx.x, group = tid >> 8, gtid = tid & 255;
   constexpr int CH = (V2_BM * V2_BH / 8 + NTH - 1) / NTH;
   float dh[CH][8], r[CH][8], z[CH][8], n[CH][8], hn[CH][8], hp[CH][8];
+  auto gather = [&]() __attribute__((always_inline)) {
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int id = tid + c * NTH;
@@ -402,29 +404,34 @@ __device__ __forceinline__ void gru_bwd2_body(const GruBwdArgs<T>& a, int bx, in
       }
     }
   }
+  };
+  if (PRE) gather();
   f32x16 acc[1][NACC];
   {
     const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NACC; ++s) acc[0][s] = zacc;
   }
-  const int nkg = ((3 * H + Cfg::BK - 1) / Cfg::BK + G - 1) / G;
-  if (a.rows_in > 0 && m0 < a.rows_in && !(a.dbg & 1)) {   // block-uniform
-    RowSrc<T> as{a.dGH_in, 3L * H, m0, a.rows_in};
-    RowSrc<T> bs{a.WhhT, 3L * H, j0, H};
-    mma_mainloop_nt<Cfg, NACC, 0>(acc, as, bs, 3 * H, smem + group * Cfg::SMEM_BYTES, gtid, group * nkg, nkg);
-  }
-  if constexpr (UP) {
-    if (a.dGI_up && !a.final_step) {   // gradient arriving from the layer above, same time step
-      RowSrc<T> as{a.dGI_up, 3L * H, m0, a.rows_out};
-      RowSrc<T> bs{a.WihT_up, 3L * H, j0, H};
-      mma_mainloop_nt<Cfg, NACC, 1>(acc, as, bs, 3 * H, smem + group * Cfg::SMEM_BYTES, gtid, group * nkg, nkg);
+  {
+    // one pipelined K loop over [dGH_{t+1} | dGI_up] against [W_hh^T | W_ih_up^T]
+    const int K1 = (a.rows_in > 0 && m0 < a.rows_in && !(a.dbg & 1)) ? 3 * H : 0;   // block-uniform
+    const int K2 = (UP && a.dGI_up && !a.final_step) ? 3 * H : 0;
+    const int nkt = (K1 + Cfg::BK - 1) / Cfg::BK + (K2 + Cfg::BK - 1) / Cfg::BK;
+    const int nkg = (nkt + G - 1) / G;
+    if (nkt > 0) {
+      RowSrc<T> a1{a.dGH_in, 3L * H, m0, a.rows_in};
+      RowSrc<T> b1{a.WhhT, 3L * H, j0, H};
+      RowSrc<T> a2{a.dGI_up, 3L * H, m0, a.rows_out};
+      RowSrc<T> b2{a.WihT_up, 3L * H, j0, H};
+      mma_mainloop_nt2<Cfg, NACC, 0, NACC - 1>(acc, a1, b1, K1, a2, b2, K2, smem + group * Cfg::SMEM_BYTES, gtid,
+                                               group * nkg, nkg);
     }
   }
   float* xt = reinterpret_cast<float*>(smem);
   if (a.dbg & 2) { if (acc[0][0][0] == 123.456f || dh[0][0] == 77.7f) a.dhz_out[0] = 1.0f; return; }
   v2_exchange<Cfg, NACC>(acc, xt, gtid, group, G);
   if (a.dbg & 8) { if (xt[tid] == 123.456f) a.dhz_out[0] = 1.0f; return; }
+  if (!PRE) gather();
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int id = tid + c * NTH;
@@ -475,14 +482,14 @@ __device__ __forceinline__ void gru_bwd2_body(const GruBwdArgs<T>& a, int bx, in
 template <typename T, int G, int D>
 __global__ __launch_bounds__(256 * G) void gru_bwd2_kernel(GruBwdArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gru_bwd2_body<T, G, D, false>(a, blockIdx.x, blockIdx.y, smem);
+  gru_bwd2_body<T, G, D, false, (G < 4)>(a, blockIdx.x, blockIdx.y, smem);
 }
 template <typename T, int G, int D>
 __global__ __launch_bounds__(256 * G) void gru_bwd2_diag_kernel(GruBwdDiag<T> d) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const GruBwdArgs<T>& a = d.a[blockIdx.z];
   if ((int)blockIdx.y * V2_BM >= a.rows_out) return;
-  gru_bwd2_body<T, G, D, true>(a, blockIdx.x, blockIdx.y, smem);
+  gru_bwd2_body<T, G, D, true, (G < 4)>(a, blockIdx.x, blockIdx.y, smem);
 }
 
 template <int MODE, int G, int D, typename T> static int launch_fwd2(const GruFwdArgs<T>& a, hipStream_t stream) {
@@ -548,7 +555,7 @@ template <typename T> int launch_gru_fwd(const GruFwdArgs<T>& a, hipStream_t str
   }
   if (a.gi_mode == PG_GI_ARRAY) return launch_fwd2<PG_GI_ARRAY, 2, 2, T>(a, stream);
   if (a.gi_mode == PG_GI_TABLE) return launch_fwd2<PG_GI_TABLE, 2, 2, T>(a, stream);
-  return launch_fwd2<PG_GI_FUSED, 2, 2, T>(a, stream);
+  return launch_fwd2<PG_GI_FUSED, 2, 1, T>(a, stream);
 }
 
 template <typename T> int launch_gru_bwd(const GruBwdArgs<T>& a, hipStream_t stream) {
@@ -556,7 +563,7 @@ template <typename T> int launch_gru_bwd(const GruBwdArgs<T>& a, hipStream_t str
   if (a.rows_out <= 0) return PG_OK;
   PG_REQUIRE(a.H % EPC == 0, "gru_bwd: hidden size %d must be a multiple of %d", a.H, EPC);
   PG_REQUIRE(a.rows_in <= a.rows_out, "gru_bwd: rows_in %d > rows_out %d (batch must be sorted by length)", a.rows_in, a.rows_out);
-  if (a.rows_out <= 4096) return launch_bwd2<4, 2, T>(a, stream);
+  if (a.rows_out <= 4096) return launch_bwd2<4, 1, T>(a, stream);
   using Cfg = TileCfg<T, 64, 64, 8, 2, 2, 1, 4>;
   dim3 grid(cdiv(a.H, Cfg::BN), cdiv(a.rows_out, Cfg::BM));
   PG_LAUNCH_BIG_SMEM(gru_bwd_kernel<Cfg>, grid, dim3(Cfg::NTHREADS), Cfg::SMEM_BYTES, stream, a);
@@ -566,7 +573,7 @@ template <typename T> int launch_gru_bwd(const GruBwdArgs<T>& a, hipStream_t str
 
 template <typename T> int launch_gru_fwd_diag(const GruFwdDiag<T>& d, hipStream_t stream) {
   if (d.n <= 0) return PG_OK;
-  constexpr int G = 2, D = 2;
+  constexpr int G = 2, D = 1;
   using Cfg = TileCfg<T, V2_BM, 3 * V2_BH, 8, 2, 2, 3, D>;
   constexpr size_t smem = (size_t)G * Cfg::SMEM_BYTES;
   int rows = 0, H = d.a[0].H;
@@ -583,7 +590,7 @@ template <typename T> int launch_gru_fwd_diag(const GruFwdDiag<T>& d, hipStream_
 }
 template <typename T> int launch_gru_bwd_diag(const GruBwdDiag<T>& d, hipStream_t stream) {
   if (d.n <= 0) return PG_OK;
-  constexpr int G = 4, D = 2;
+  constexpr int G = 4, D = 1;
   using Cfg = TileCfg<T, V2_BM, V2_BH, 8, 2, 2, 1, D>;
   constexpr size_t smem = (size_t)G * Cfg::SMEM_BYTES;
   static_assert(smem >= 2 * V2_BM * V2_LD * 4, "exchange tiles must fit the staging LDS");

@@ -204,6 +204,120 @@ __device__ __forceinline__ void mma_mainloop_nt(f32x16 (&acc)[Cfg::TM][NACC], co
   }
 }
 
+// Two operand pairs contracted in ONE pipelined K loop (no second pipeline fill): virtual K tiles 0..nk1-1 come from
+// (a1, b1) with the last gate routed to accumulator slot SLOT1, tiles nk1.. from (a2, b2) routed to SLOT2.  Used by the
+// fused GRU cells: h.W_hh^T then x.W_ih^T (forward), dGH.W_hh then dGI_up.W_ih_up (backward).  K2 = 0 disables pair 2.
+// The group contracts virtual tiles kt_begin .. kt_begin+nk-1 (same nk for every K-group of the block).
+template <class Cfg, int NACC, int SLOT1, int SLOT2, class ASrc1, class BSrc1, class ASrc2, class BSrc2>
+__device__ __forceinline__ void mma_mainloop_nt2(f32x16 (&acc)[Cfg::TM][NACC], const ASrc1& a1, const BSrc1& b1, int K1,
+                                                 const ASrc2& a2, const BSrc2& b2, int K2, char* smem, int tid,
+                                                 int kt_begin, int nk) {
+  using T = typename Cfg::T;
+  constexpr int NT = Cfg::NTHREADS, BKC = Cfg::BKC, EPC = Cfg::EPC, ROWB = Cfg::ROWB;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int nk1 = (K1 + Cfg::BK - 1) / Cfg::BK;
+  const __amdgpu_buffer_rsrc_t ar1 = pg_make_rsrc(a1.base), br1 = pg_make_rsrc(b1.base);
+  const __amdgpu_buffer_rsrc_t ar2 = pg_make_rsrc(K2 > 0 ? a2.base : a1.base), br2 = pg_make_rsrc(K2 > 0 ? b2.base : b1.base);
+  unsigned pa1[Cfg::A_IT], pb1[Cfg::B_IT], pa2[Cfg::A_IT], pb2[Cfg::B_IT];
+  int oa[Cfg::A_IT], ob[Cfg::B_IT];
+#pragma unroll
+  for (int i = 0; i < Cfg::A_IT; ++i) {
+    int id = tid + i * NT;
+    int row = id / BKC, c = id % BKC;
+    bool ok = id < Cfg::BM * BKC;
+    long o1 = ok ? a1(row) : -1L, o2 = (ok && K2 > 0) ? a2(row) : -1L;
+    pa1[i] = o1 >= 0 ? (unsigned)((o1 + c * EPC) * (long)sizeof(T)) : PG_OOB;
+    pa2[i] = o2 >= 0 ? (unsigned)((o2 + c * EPC) * (long)sizeof(T)) : PG_OOB;
+    oa[i] = ok ? row * ROWB + c * 16 : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < Cfg::B_IT; ++i) {
+    int id = tid + i * NT;
+    int row = id / BKC, c = id % BKC;
+    bool ok = id < Cfg::BN * BKC;
+    long o1 = ok ? b1(row) : -1L, o2 = (ok && K2 > 0) ? b2(row) : -1L;
+    pb1[i] = o1 >= 0 ? (unsigned)((o1 + c * EPC) * (long)sizeof(T)) : PG_OOB;
+    pb2[i] = o2 >= 0 ? (unsigned)((o2 + c * EPC) * (long)sizeof(T)) : PG_OOB;
+    ob[i] = ok ? row * ROWB + c * 16 : -1;
+  }
+  constexpr int D = Cfg::DEPTH;
+  uint4 ra[D][Cfg::A_IT], rb[D][Cfg::B_IT];
+  const int vend = kt_begin + nk;
+  auto gload = [&](int kt, auto slot_c) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slot_c)::value;
+    const int v = kt_begin + kt;                 // virtual tile (block-uniform)
+    const bool seg2 = v >= nk1;
+    const int k0 = (seg2 ? v - nk1 : v) * Cfg::BK;
+    const int kend = v < vend ? (seg2 ? K2 : K1) : 0;
+    const unsigned soff = (unsigned)k0 * (unsigned)sizeof(T);
+    const __amdgpu_buffer_rsrc_t ar = seg2 ? ar2 : ar1, br = seg2 ? br2 : br1;
+#pragma unroll
+    for (int i = 0; i < Cfg::A_IT; ++i) {
+      int c = (tid + i * NT) % BKC;
+      ra[slot][i] = pg_buf_load16(ar, (k0 + c * EPC < kend) ? (seg2 ? pa2[i] : pa1[i]) : PG_OOB, soff);
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::B_IT; ++i) {
+      int c = (tid + i * NT) % BKC;
+      rb[slot][i] = pg_buf_load16(br, (k0 + c * EPC < kend) ? (seg2 ? pb2[i] : pb1[i]) : PG_OOB, soff);
+    }
+  };
+  auto sstore = [&](int buf, auto slot_c) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slot_c)::value;
+    char* sa = smem + buf * Cfg::STAGE_BYTES;
+    char* sb = sa + Cfg::A_BYTES;
+#pragma unroll
+    for (int i = 0; i < Cfg::A_IT; ++i)
+      if (oa[i] >= 0) *reinterpret_cast<uint4*>(sa + oa[i]) = ra[slot][i];
+#pragma unroll
+    for (int i = 0; i < Cfg::B_IT; ++i)
+      if (ob[i] >= 0) *reinterpret_cast<uint4*>(sb + ob[i]) = rb[slot][i];
+  };
+  const int lr = lane & 31, lh = lane >> 5;
+  auto compute = [&](int buf, auto slot_last_c) __attribute__((always_inline)) {
+    constexpr int SLOT_LAST = decltype(slot_last_c)::value;
+    const char* sa = smem + buf * Cfg::STAGE_BYTES;
+    const char* sb = sa + Cfg::A_BYTES;
+#pragma unroll
+    for (int s = 0; s < BKC / 2; ++s) {
+      uint4 fa[Cfg::TM], fb[Cfg::TN];
+#pragma unroll
+      for (int tm = 0; tm < Cfg::TM; ++tm)
+        fa[tm] = *reinterpret_cast<const uint4*>(sa + (wm * Cfg::WTM + tm * 32 + lr) * ROWB + (s * 2 + lh) * 16);
+#pragma unroll
+      for (int tn = 0; tn < Cfg::TN; ++tn) {
+        int brow = Cfg::gate_of(tn) * Cfg::BNG + Cfg::col_in_group(wn, tn, lr);
+        fb[tn] = *reinterpret_cast<const uint4*>(sb + brow * ROWB + (s * 2 + lh) * 16);
+      }
+#pragma unroll
+      for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < Cfg::TN; ++tn) {
+          constexpr int TU = Cfg::TU;
+          const int slot = (tn / TU == Cfg::NGATE - 1) ? SLOT_LAST * TU + tn % TU : tn;
+          MmaOp<T>::run(acc[tm][slot], fa[tm], fb[tn]);
+        }
+    }
+  };
+  static_for<D>([&](auto d) __attribute__((always_inline)) { gload(decltype(d)::value, d); });
+  sstore(0, IntC<0>{});
+  __syncthreads();
+  for (int kt0 = 0; kt0 < nk; kt0 += D) {
+    static_for<D>([&](auto d) __attribute__((always_inline)) {
+      constexpr int dd = decltype(d)::value;
+      const int kt = kt0 + dd;
+      if (kt < nk) {                               // block-uniform
+        gload(kt + D, d);
+        if (kt_begin + kt >= nk1) compute(kt & 1, IntC<SLOT2>{});
+        else compute(kt & 1, IntC<SLOT1>{});
+        sstore((kt + 1) & 1, IntC<(dd + 1) % D>{});
+        __syncthreads();
+      }
+    });
+  }
+}
+
 template <class Cfg, int NACC, int SLOT_LAST, class ASrc, class BSrc>
 __device__ __forceinline__ void mma_mainloop_nt(f32x16 (&acc)[Cfg::TM][NACC], const ASrc& asrc, const BSrc& bsrc,
                                                 int K, char* smem) {
