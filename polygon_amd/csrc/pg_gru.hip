@@ -257,7 +257,8 @@ __device__ __forceinline__ void gru_fwd2_body(const GruFwdArgs<T>& a, int bx, in
   const int MODE = MODE_T == PG_GI_DYN ? a.gi_mode : MODE_T;   // block-uniform
   const int H = a.H;
   const int j0 = bx * V2_BH, m0 = by * V2_BM;
-  const int tid = threadIdx.x, group = tid >> 8, gtid = tid & 255;
+  const int tid = threadIdx.x, gtid = tid & 255;
+  const int group = __builtin_amdgcn_readfirstlane(tid >> 8);   // wave-uniform, and provably so (scalar descriptors/offsets)
   // ---- epilogue assignment + input prefetch: chunk c covers row c/8, columns 8*(c%8)..+7 of the 64x64 tile
   constexpr int CH = (V2_BM * V2_BH / 8 + NTH - 1) / NTH;
   float gr[CH][8], gz[CH][8], gn[CH][8], hp[CH][8];
@@ -375,7 +376,8 @@ __device__ __forceinline__ void gru_bwd2_body(const GruBwdArgs<T>& a, int bx, in
   constexpr int NACC = UP ? 2 : 1;
   const int H = a.H;
   const int j0 = bx * V2_BH, m0 = by * V2_BM;
-  const int tid = threadIdx.x, group = tid >> 8, gtid = tid & 255;
+  const int tid = threadIdx.x, gtid = tid & 255;
+  const int group = __builtin_amdgcn_readfirstlane(tid >> 8);   // wave-uniform, and provably so (scalar descriptors/offsets)
   constexpr int CH = (V2_BM * V2_BH / 8 + NTH - 1) / NTH;
   float dh[CH][8], r[CH][8], z[CH][8], n[CH][8], hn[CH][8], hp[CH][8];
   auto gather = [&]() __attribute__((always_inline)) {

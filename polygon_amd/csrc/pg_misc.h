@@ -147,9 +147,10 @@ template <typename T>
 static __global__ void ce_kernel(const float* __restrict__ logits, const int* __restrict__ tgt, long N, int V, int Vp, int pad,
                           T* __restrict__ dlogits, float* __restrict__ scal) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const long r = (long)blockIdx.x * (blockDim.x >> 6) + wv;
+  const int nw = blockDim.x >> 6;
   float loss = 0.0f, cnt = 0.0f;
-  if (r < N) {
+  // grid-stride over rows, one wave per row: few blocks => few atomics on the two loss words
+  for (long r = (long)blockIdx.x * nw + wv; r < N; r += (long)gridDim.x * nw) {
     const float x = lane < V ? logits[r * Vp + lane] : -INFINITY;
     const float mx = wave_max(x);
     const float e = lane < V ? __expf(x - mx) : 0.0f;
@@ -157,7 +158,7 @@ static __global__ void ce_kernel(const float* __restrict__ logits, const int* __
     const int tg = tgt[r];
     const bool w = tg != pad;
     const float xt = __shfl(x, tg < 64 ? tg : 0, 64);
-    if (w) { loss = __logf(s) + mx - xt; cnt = 1.0f; }
+    if (w) { loss += __logf(s) + mx - xt; cnt += 1.0f; }
     if (dlogits && lane < Vp) {
       const float p = e / s;
       dlogits[r * Vp + lane] = from_f32<T>(w && lane < V ? p - (lane == tg ? 1.0f : 0.0f) : 0.0f);

@@ -102,7 +102,8 @@ template <typename T_, int BM_, int BN_, int BKC_, int WM_, int WN_, int NGATE_ 
 // second pass route the n-gate to a separate accumulator).  Leaves the block synchronised (LDS reusable).
 template <class Cfg, int NACC, int SLOT_LAST, class ASrc, class BSrc>
 __device__ __forceinline__ void mma_mainloop_nt(f32x16 (&acc)[Cfg::TM][NACC], const ASrc& asrc, const BSrc& bsrc,
-                                                int K, char* smem, int tid, int kt_begin, int nk) {
+                                                int K, char* smem, int tid, int kt_begin_, int nk) {
+  const int kt_begin = __builtin_amdgcn_readfirstlane(kt_begin_);
   // tid: thread index inside the K-group (Cfg::NTHREADS threads share `smem`); the group contracts K tiles
   // kt_begin .. kt_begin+nk-1.  Every K-group of a block must pass the same nk (the barriers are block-wide).
   using T = typename Cfg::T;
@@ -211,9 +212,10 @@ __device__ __forceinline__ void mma_mainloop_nt(f32x16 (&acc)[Cfg::TM][NACC], co
 template <class Cfg, int NACC, int SLOT1, int SLOT2, class ASrc1, class BSrc1, class ASrc2, class BSrc2>
 __device__ __forceinline__ void mma_mainloop_nt2(f32x16 (&acc)[Cfg::TM][NACC], const ASrc1& a1, const BSrc1& b1, int K1,
                                                  const ASrc2& a2, const BSrc2& b2, int K2, char* smem, int tid,
-                                                 int kt_begin, int nk) {
+                                                 int kt_begin_, int nk) {
   using T = typename Cfg::T;
   constexpr int NT = Cfg::NTHREADS, BKC = Cfg::BKC, EPC = Cfg::EPC, ROWB = Cfg::ROWB;
+  const int kt_begin = __builtin_amdgcn_readfirstlane(kt_begin_);   // keeps descriptor selects / soffsets scalar
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   const int nk1 = (K1 + Cfg::BK - 1) / Cfg::BK;
