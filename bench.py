@@ -46,10 +46,9 @@ def hip_events_ms(fn, stream, iters):
     return start.elapsed_time(end) / iters
 
 
-def roofline_gate_gemm(dtype, B, H):
-    """Dominant kernel (rocprof: profiles/): the BPTT step kernel gru_bwd2_kernel = gate-gradient GEMM
-    [B,3H]x[3H,H] on MFMA + fused gate-gradient epilogue.  Timed live with HIP events on the stream it is launched on
-    (a C-side loop of launches through pg_bench_gru, rows = B).  Algorithmic flop per launch = 2*B*3H*H."""
+def step_kernel_microbench(dtype, B, H):
+    """Isolated single-cell step kernels (gru_fwd2_kernel / gru_bwd2_kernel) at rows = B, a C-side loop of launches
+    through pg_bench_gru timed with HIP events on the launch stream: the per-launch latency floor of the recurrence."""
     code = _lib.PG_BF16 if dtype == "bf16" else _lib.PG_F32
     L = _lib.lib()
     nbytes = 80 * B * H + 16 * H * H + (1 << 20)
@@ -64,13 +63,48 @@ def roofline_gate_gemm(dtype, B, H):
         return hip_events_ms(fn, st, 3) / reps
     ms_bwd, ms_fwd = run(1), run(0)
     flops = 2.0 * B * H * 3 * H
-    ach = flops / (ms_bwd * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gru_bwd2_kernel (BPTT step: dGH[%d,%d] x W_hh[%d,%d] + gate-gradient epilogue)" % (B, 3 * H, 3 * H, H),
-            "achieved": ach, "peak": PEAK[dtype], "unit": "TFLOP/s", "frac": ach / PEAK[dtype], "traffic": None,
-            "avg_launch_us": ms_bwd * 1e3, "flop_per_launch": flops,
-            "fwd_step_kernel": {"kernel": "gru_fwd2_kernel", "avg_launch_us": ms_fwd * 1e3,
-                                "achieved": flops / (ms_fwd * 1e-3) / 1e12},
-            "note": "step kernels are latency-bound (launch floor ~2.6 us + operand fetch + short K loop), see DESIGN.md 3"}
+    return {"rows": B, "flop_per_launch": flops,
+            "bwd_cell": {"kernel": "gru_bwd2_kernel", "avg_launch_us": ms_bwd * 1e3, "tflops": flops / (ms_bwd * 1e-3) / 1e12},
+            "fwd_cell": {"kernel": "gru_fwd2_kernel", "avg_launch_us": ms_fwd * 1e3, "tflops": flops / (ms_fwd * 1e-3) / 1e12}}
+
+
+def profile_read(which):
+    L = _lib.lib()
+    ms, n, fl, seg = ctypes.c_double(), ctypes.c_long(), ctypes.c_double(), ctypes.c_int()
+    _lib.check(L.pg_profile_read(which, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(seg)))
+    return ms.value, n.value, fl.value, seg.value
+
+
+def pmc_traffic(kernel, dtype):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE); None when not measured for dtype."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            t = json.load(f)
+        k = t.get(dtype, {}).get(kernel)
+        return float(k["hbm_bytes_per_launch"]) if k else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def roofline_recurrence(dtype):
+    """Dominant kernel (profiles/r01_bench_kernel_stats.md): gru_bwd2_diag_kernel, one launch per anti-diagonal of the
+    decoder's (layer, t) BPTT grid = up to 3 cells, each dh = dGH_{t+1}.W_hh (+ dGI_{l+1,t}.W_ih_{l+1}) on MFMA with the
+    gate-gradient epilogue fused.  Measured LIVE over the timed region: pg_decoder_bwd brackets its wavefront loop (which
+    launches only this kernel) with a HIP event pair on the launch stream; avg launch = event time / launches,
+    algorithmic flop = 2*3H*H*(rows_in + rows_out[layers below the top]) summed over the cells."""
+    ms_b, n_b, fl_b, seg_b = profile_read(1)
+    ms_f, n_f, fl_f, seg_f = profile_read(0)
+    ach = fl_b / (ms_b * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gru_bwd2_diag_kernel (BPTT anti-diagonal: dh = dGH.W_hh + dGI_up.W_ih_up, gate-gradient epilogue)",
+            "achieved": ach, "peak": PEAK[dtype], "unit": "TFLOP/s", "frac": ach / PEAK[dtype],
+            "traffic": pmc_traffic("gru_bwd2_diag_kernel", dtype),
+            "avg_launch_us": ms_b / n_b * 1e3, "launches": n_b, "segments": seg_b, "flop_per_launch": fl_b / n_b,
+            "fwd_recurrence": {"kernel": "gru_fwd2_diag_kernel", "avg_launch_us": ms_f / n_f * 1e3, "launches": n_f,
+                               "flop_per_launch": fl_f / n_f, "achieved": fl_f / (ms_f * 1e-3) / 1e12,
+                               "traffic": pmc_traffic("gru_fwd2_diag_kernel", dtype)},
+            "note": "the recurrence is a chain of T+L dependent launches of ~1-3 GFLOP each: latency-bound (launch floor "
+                    "~2.6 us + operand fetch + K loop of 8-16 MFMA steps), not MFMA-throughput-bound; see DESIGN.md 3"}
 
 
 def cpu_baseline(n_strings=192):
@@ -154,11 +188,18 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
+    if rank == 0 and not args.no_roofline:   # two event records per recurrence per step, read after the timed region
+        _lib.check(_lib.lib().pg_profile_enable(1))
+        profile_read(0), profile_read(1)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        _lib.check(_lib.lib().pg_profile_enable(0))
+        roofline = roofline_recurrence(args.dtype)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -203,8 +244,9 @@ def main():
             "last_losses": {"kl": kl, "recon": recon},
             "sample": sample,
         }
-        if not args.no_roofline:
-            out["roofline"] = roofline_gate_gemm(args.dtype, args.n_batch, 512)
+        if roofline is not None:
+            out["roofline"] = roofline
+            out["roofline"]["single_cell_microbench"] = step_kernel_microbench(args.dtype, args.n_batch, 512)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

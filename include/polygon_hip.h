@@ -123,6 +123,15 @@ PG_API int pg_gemm_tn(int dtype, const void* A, long lda, const void* B, long ld
  * with HIP events, and by the kernel-tuning scripts under tools/. */
 PG_API int pg_bench_gru(int dtype, int which, int rows, int H, void* ws, size_t ws_bytes, int repeat, void* stream);
 
+/* Measurement hook (no reference counterpart): while enabled, pg_decoder_fwd / pg_decoder_bwd bracket their
+ * recurrence (the wavefront loop, which launches nothing but the diagonal step kernel) with a HIP event pair
+ * recorded on the caller's stream and count the loop's launches and algorithmic flop.  pg_profile_read waits for
+ * the recorded events, returns the sums since the last read for which = 0 (forward recurrence,
+ * gru_fwd2_diag_kernel) or 1 (BPTT recurrence, gru_bwd2_diag_kernel) and clears that side.  At most 512 segments
+ * are kept per side between reads; later ones are dropped (not counted). */
+PG_API int pg_profile_enable(int on);
+PG_API int pg_profile_read(int which, double* total_ms, long* launches, double* flop, int* segments);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,63 @@ static inline int ew_blocks(long n) { return (int)std::min<long>(cdiv(n, 256), 4
 // ===================================================================================================
 // shadow weights
 // ===================================================================================================
+// ===================================================================================================
+// measurement hook: event pairs around the two recurrences
+// ===================================================================================================
+namespace {
+constexpr int PROF_MAX = 512;
+struct ProfSide {
+  hipEvent_t e0[PROF_MAX], e1[PROF_MAX];
+  int created = 0, n = 0;
+  long launches = 0;
+  double flop = 0.0;
+};
+int g_prof_on = 0;
+ProfSide g_prof[2];
+
+// returns the slot to close with prof_end, or -1 when profiling is off / full
+int prof_begin(int which, hipStream_t st) {
+  if (!g_prof_on) return -1;
+  ProfSide& p = g_prof[which];
+  if (p.n >= PROF_MAX) return -1;
+  if (p.n >= p.created) {
+    if (hipEventCreate(&p.e0[p.created]) != hipSuccess || hipEventCreate(&p.e1[p.created]) != hipSuccess) return -1;
+    ++p.created;
+  }
+  if (hipEventRecord(p.e0[p.n], st) != hipSuccess) return -1;
+  return p.n;
+}
+void prof_end(int which, int slot, hipStream_t st, long launches, double flop) {
+  if (slot < 0) return;
+  ProfSide& p = g_prof[which];
+  if (hipEventRecord(p.e1[slot], st) != hipSuccess) return;
+  p.n = slot + 1; p.launches += launches; p.flop += flop;
+}
+}  // namespace
+
+extern "C" int pg_profile_enable(int on) {
+  g_prof_on = on ? 1 : 0;
+  return PG_OK;
+}
+
+extern "C" int pg_profile_read(int which, double* total_ms, long* launches, double* flop, int* segments) {
+  PG_REQUIRE(which == 0 || which == 1, "pg_profile_read: which must be 0 (forward) or 1 (backward)");
+  ProfSide& p = g_prof[which];
+  double ms = 0.0;
+  for (int i = 0; i < p.n; ++i) {
+    PG_CHECK_HIP(hipEventSynchronize(p.e1[i]));
+    float m = 0.0f;
+    PG_CHECK_HIP(hipEventElapsedTime(&m, p.e0[i], p.e1[i]));
+    ms += m;
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = p.launches;
+  if (flop) *flop = p.flop;
+  if (segments) *segments = p.n;
+  p.n = 0; p.launches = 0; p.flop = 0.0;
+  return PG_OK;
+}
+
 extern "C" size_t pg_shadow_bytes(const pg_dims* d, int dtype) {
   if (check_dims(d, dtype) != PG_OK) return 0;
   return shadow_offsets(d, dtype).total;
@@ -240,6 +297,8 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
   // Wavefront over the (layer, t) grid: cell (l, t) needs (l, t-1) and (l-1, t), so all cells of one anti-diagonal
   // are independent and run in ONE launch; layers >= 1 take their input projection fused (x = output of the layer
   // below at the same step).  T + L - 1 sequential launches instead of T * L.
+  const int pslot = prof_begin(0, st);
+  double pflop = 0.0;
   for (int dgi = 0; dgi < sd.T + L - 1; ++dgi) {
     GruFwdDiag<T> dg;
     for (int l = 0; l < L; ++l) {
@@ -276,8 +335,11 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
         a.p_drop = p_drop; a.seed = seed; a.layer = l; a.t = t; a.b_mul = b_mul; a.b_add = b_add;
       }
     }
+    for (int i = 0; i < dg.n; ++i)   // algorithmic flop: gates = h_prev.W_hh^T (+ x.W_ih^T when fused)
+      pflop += 2.0 * dg.a[i].rows * 3.0 * Hd * (Hd + (dg.a[i].gi_mode == PG_GI_FUSED ? dg.a[i].Kx : 0));
     PG_TRY(launch_gru_fwd_diag<T>(dg, st));
   }
+  prof_end(0, pslot, st, sd.T + L - 1, pflop);
   {  // vocab projection
     GemmEpi<T> e;
     e.bias = at<float>(shadow, so.fc_b); e.C32 = at<float>(ws, w.d_logits); e.ldc = Vp;
@@ -340,6 +402,8 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   const bool drop = p_drop > 0.0f;
   // BPTT as a wavefront: cell (l, t) needs (l, t+1) and (l+1, t); the gradient coming down from layer l+1 is
   // computed inside the cell (dGI_{l+1,t} . W_ih_{l+1}, through layer l's dropout mask), so no per-layer dX GEMM.
+  const int pslot = prof_begin(1, st);
+  double pflop = 0.0;
   for (int dgi = 0; dgi < sd.T + L; ++dgi) {
     GruBwdDiag<T> dg;
     for (int l = L - 1; l >= 0; --l) {
@@ -374,8 +438,11 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
         a.dh0_accumulate = (l != L - 1);
       }
     }
+    for (int i = 0; i < dg.n; ++i)   // algorithmic flop: dh = dGH_{t+1}.W_hh (+ dGI_{l+1,t}.W_ih_{l+1} from the layer above)
+      pflop += 2.0 * 3.0 * Hd * Hd * (dg.a[i].rows_in + (dg.a[i].dGI_up ? dg.a[i].rows_out : 0));
     PG_TRY(launch_gru_bwd_diag<T>(dg, st));
   }
+  prof_end(1, pslot, st, sd.T + L, pflop);
   for (int l = L - 1; l >= 0; --l) {
     T* dGI = at<T>(ws, w.b_dGI_l[l]);
     T* dGH = at<T>(ws, w.b_dGH_l[l]);

@@ -148,3 +148,39 @@ def test_plain_tensor_list_input():
     assert abs(recon.item() - dec["recon"]) <= 1e-3 * abs(dec["recon"])
     mu = model.encode(xs)
     assert rel_err(mu, enc["mu"]) <= 1e-3
+
+
+def test_profile_hook_counts_recurrence_launches():
+    """pg_profile_enable / pg_profile_read: one event pair per recurrence, T+L-1 forward and T+L backward launches."""
+    import ctypes
+    from polygon_amd import _lib
+    L = _lib.lib()
+    model, _ = build_model(TINY, 1, "fp32")
+    model.eval()
+    strings = ["CCCCCC", "CCCC", "CC"]          # decoder steps T = len+2-1 = 7
+    batch = model.get_collate_fn()(list(strings))
+    _lib.check(L.pg_profile_enable(1))
+    try:
+        kl, recon = model(batch)
+        (kl + recon).backward()
+        out = []
+        for which in (0, 1):
+            ms, n, fl, seg = ctypes.c_double(), ctypes.c_long(), ctypes.c_double(), ctypes.c_int()
+            _lib.check(L.pg_profile_read(which, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(seg)))
+            out.append((ms.value, n.value, fl.value, seg.value))
+    finally:
+        _lib.check(L.pg_profile_enable(0))
+    T, Ld, H = 7, TINY["L"], TINY["Hd"]
+    rows = [3, 3, 3, 2, 2, 1, 1]                 # sequences still running at decoder step t (lengths 8, 6, 4)
+    assert out[0][1] == T + Ld - 1 and out[1][1] == T + Ld and out[0][3] == 1 and out[1][3] == 1
+    assert out[0][0] > 0 and out[1][0] > 0
+    # forward: every layer's h_prev.W_hh^T, plus the fused x.W_ih^T of layers >= 1 (layer 0 gathers its table)
+    fwd = sum(2.0 * r * 3 * H * (Ld * H + (Ld - 1) * H) for r in rows)
+    assert abs(out[0][2] - fwd) <= 1e-6 * fwd
+    bwd = sum(2.0 * 3 * H * H * (Ld * rows[t + 1] if t + 1 < T else 0) for t in range(-1, T)) + \
+        sum(2.0 * 3 * H * H * (Ld - 1) * r for r in rows)
+    assert abs(out[1][2] - bwd) <= 1e-6 * bwd
+    # a second read returns nothing
+    ms, n, fl, seg = ctypes.c_double(), ctypes.c_long(), ctypes.c_double(), ctypes.c_int()
+    _lib.check(L.pg_profile_read(1, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(seg)))
+    assert n.value == 0 and seg.value == 0
