@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 (ROCm 7.2 rocpd sqlite output) runs into the files kept under profiles/.
+
+  python tools/rocpd_summary.py stats  <kernel-trace results.db> <out.csv> <out.md> [title]
+  python tools/rocpd_summary.py traffic <FETCH_SIZE results.db> <WRITE_SIZE results.db> <out.json> <dtype>
+
+`traffic` applies the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts 128-byte
+read requests at 64 bytes, so it is doubled; WRITE_SIZE is exact for 16-byte-per-lane stores.  Both counters are in KiB
+and sit on the L2's memory side, i.e. Infinity-Cache hits are included."""
+import json
+import sqlite3
+import sys
+
+
+def stats(db, out_csv, out_md, title):
+    c = sqlite3.connect(db)
+    rows = c.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
+                     "from kernels group by name order by sum(duration) desc").fetchall()
+    tot = sum(r[2] for r in rows)
+    with open(out_csv, "w") as f:
+        f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+        for r in rows:
+            f.write('"%s",%d,%d,%.1f,%.2f,%d,%d\n' % (r[0], r[1], r[2], r[3], 100.0 * r[2] / tot, r[4], r[5]))
+    with open(out_md, "w") as f:
+        f.write("# %s\n\n| kernel | calls | total ms | avg us | %% |\n|---|---:|---:|---:|---:|\n" % title)
+        for r in rows[:25]:
+            f.write("| `%s` | %d | %.2f | %.2f | %.1f |\n" % (r[0][:110], r[1], r[2] / 1e6, r[3] / 1e3, 100.0 * r[2] / tot))
+
+
+def traffic(db_f, db_w, out_json, dtype):
+    def per_kernel(db, name):
+        c = sqlite3.connect(db)
+        return {r[0]: (r[1], r[2]) for r in c.execute(
+            "select kernel_name, count(*), avg(value) from counters_collection where counter_name=? group by kernel_name", (name,))}
+    F, W = per_kernel(db_f, "FETCH_SIZE"), per_kernel(db_w, "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(F) | set(W)):
+        short = k
+        for tag in ("gru_bwd2_diag_kernel", "gru_fwd2_diag_kernel", "gru_bwd2_kernel", "gru_fwd2_kernel", "gemm_tn_kernel",
+                    "gemm_nt_kernel", "colsum_kernel", "ce_kernel", "adam_kernel", "sample_head_kernel"):
+            if tag in k:
+                short = tag
+        f_kib = F.get(k, (0, 0.0))[1]
+        w_kib = W.get(k, (0, 0.0))[1]
+        e = out.setdefault(short, {"launches": 0, "fetch_bytes_raw": 0.0, "write_bytes": 0.0})
+        n = max(F.get(k, (0, 0))[0], W.get(k, (0, 0))[0])
+        e["fetch_bytes_raw"] += f_kib * 1024 * n
+        e["write_bytes"] += w_kib * 1024 * n
+        e["launches"] += n
+    for e in out.values():
+        n = e["launches"]
+        e["fetch_bytes_raw"] /= n
+        e["write_bytes"] /= n
+        e["fetch_bytes_corrected"] = 2.0 * e["fetch_bytes_raw"]
+        e["hbm_bytes_per_launch"] = e["fetch_bytes_corrected"] + e["write_bytes"]
+    with open(out_json, "w") as f:
+        json.dump({"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 2 "
+                           "--warmup 1 --no_cpu_baseline --no_roofline --sample_n 0`; per-launch averages; FETCH_SIZE doubled "
+                           "(gfx950 correction, MI355X_MICROARCH.md); memory-side-of-L2 counters, Infinity-Cache hits included",
+                   dtype: out}, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "rocprofv3 --kernel-trace --stats")
+    else:
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
