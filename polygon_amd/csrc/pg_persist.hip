@@ -1,0 +1,326 @@
+// Row-resident persistent encoder recurrence (see pg_persist.h).  bf16 operands, fp32 state and accumulation.
+//
+// Geometry (H = 256): block = 16 sequences x all H units, 8 waves; wave w owns units [32w, 32w+32) as two 16-unit MFMA
+// tiles.  MFMA v_mfma_f32_16x16x32_bf16 is issued with the WEIGHTS as its first operand and the activations as its second,
+// so the accumulator tile is [unit][sequence]: lane (lr = lane & 15, lq = lane >> 4) holds units 4lq..4lq+3 of sequence lr.
+// Four consecutive units per lane make every global access of the epilogue an 8-byte (bf16x4) or 16-byte (float4) one.
+#include <hip/hip_runtime.h>
+#include "pg_persist.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+
+namespace {
+
+constexpr int PR = 16;   // sequences per block
+
+__device__ __forceinline__ f32x4 mma16(const bf16x8& w, const bf16x8& x, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x4 to_bf16x4(const float (&v)[4]) {
+  bf16x4 o;
+  o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+  return o;
+}
+
+template <int H> struct PersistGeo {
+  static constexpr int NW = H / 32;              // waves
+  static constexpr int NTH = 64 * NW;
+  static constexpr int KS_H = H / 32;            // MFMA K steps over a K = H contraction
+  static constexpr int ROWB_H = H * 2 + 16;      // padded LDS row of H bf16
+  static constexpr int ROWB_3H = 3 * H * 2 + 16;
+  static constexpr int WN_BYTES = H * ROWB_H;    // n-gate weight rows kept in LDS
+  static constexpr int FWD_SMEM = WN_BYTES + 2 * PR * ROWB_H;
+  static constexpr int BWD_SMEM = WN_BYTES + PR * ROWB_3H;
+};
+
+// steps this block runs = length of its longest (first) sequence = #t with B_t > row0 (B_t is non-increasing)
+__device__ __forceinline__ int block_steps(const Sched& sd, int row0) {
+  int n = 0;
+  while (n < sd.T && sd.off[n + 1] - sd.off[n] > row0) ++n;
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(PersistGeo<H>::NTH) void enc_fwd_persist_kernel(EncFwdPersist a, Sched sd) {
+  using G = PersistGeo<H>;
+  constexpr int KS = G::KS_H, ROWB = G::ROWB_H;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sWn = smem;                 // [H][ROWB]   W_hn rows
+  char* sA = smem + G::WN_BYTES;    // [2][PR][ROWB] bf16 state tile, double buffered
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int row0 = blockIdx.x * PR;
+  const int b = row0 + lr;                       // this lane's sequence
+  const int Tb = block_steps(sd, row0);
+  const int u0 = wave * 32 + lq * 4;             // first unit of tile 0 held by this lane (tile 1: +16)
+
+  // ---- stationary weights: r and z rows of this wave's units -> registers, every n row -> LDS
+  bf16x8 wreg[2][2][KS];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        wreg[g][nt][ks] = *reinterpret_cast<const bf16x8*>(a.Whh + (long)(g * H + wave * 32 + nt * 16 + lr) * H + (ks * 4 + lq) * 8);
+  for (int c = tid; c < H * (H / 8); c += G::NTH) {
+    const int u = c / (H / 8), ch = c % (H / 8);
+    *reinterpret_cast<uint4*>(sWn + u * ROWB + ch * 16) = *reinterpret_cast<const uint4*>(a.Whh + (long)(2 * H + u) * H + ch * 8);
+  }
+  for (int c = tid; c < 2 * PR * ROWB / 16; c += G::NTH) reinterpret_cast<uint4*>(sA)[c] = make_uint4(0, 0, 0, 0);
+  float bh[2][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bh[nt][i] = a.bhn[u0 + nt * 16 + i];
+
+  float h[2][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[nt][i] = 0.0f;
+
+  // token of this lane's sequence at step t (0 when the sequence is over: any valid table row, the value is unused)
+  auto token_at = [&](int t) __attribute__((always_inline)) -> int {
+    if (t >= Tb) return 0;
+    const int o = sd.off[t], Bt = sd.off[t + 1] - o;
+    return b < Bt ? a.tok[o + b] : 0;
+  };
+  auto gather = [&](int tok, f32x4 (&gi)[3][2]) __attribute__((always_inline)) {
+    const float* p = a.table + (long)tok * 3 * H + u0;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) gi[g][nt] = *reinterpret_cast<const f32x4*>(p + g * H + nt * 16);
+  };
+  f32x4 gi[3][2];
+  gather(token_at(0), gi);
+  int tok_next = token_at(1);
+  __syncthreads();
+
+  for (int t = 0; t < Tb; ++t) {
+    const int cur = t & 1;
+    // prefetch: gather-table rows of step t+1, token of step t+2
+    f32x4 gin[3][2];
+    gather(tok_next, gin);
+    tok_next = token_at(t + 2);
+    // gates: acc[g][nt][unit 4lq+i][sequence lr] = sum_k W[g*H + unit][k] * h_{t-1}[sequence][k]
+    f32x4 acc[3][2];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[g][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* A = sA + cur * (PR * ROWB) + lr * ROWB + lq * 16;
+    const char* Wn = sWn + (wave * 32 + lr) * ROWB + lq * 16;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 x = *reinterpret_cast<const bf16x8*>(A + ks * 64);
+      const bf16x8 n0 = *reinterpret_cast<const bf16x8*>(Wn + ks * 64);
+      const bf16x8 n1 = *reinterpret_cast<const bf16x8*>(Wn + 16 * ROWB + ks * 64);
+      acc[0][0] = mma16(wreg[0][0][ks], x, acc[0][0]);
+      acc[0][1] = mma16(wreg[0][1][ks], x, acc[0][1]);
+      acc[1][0] = mma16(wreg[1][0][ks], x, acc[1][0]);
+      acc[1][1] = mma16(wreg[1][1][ks], x, acc[1][1]);
+      acc[2][0] = mma16(n0, x, acc[2][0]);
+      acc[2][1] = mma16(n1, x, acc[2][1]);
+    }
+    // epilogue on this lane's 2 x 4 units of sequence b
+    const int o = sd.off[t], Bt = sd.off[t + 1] - o;
+    const bool live = b < Bt;
+    char* An = sA + (cur ^ 1) * (PR * ROWB) + lr * ROWB;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      float r[4], z[4], n[4], hn[4], hp[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        hp[i] = h[nt][i];
+        r[i] = sigmoidf_(gi[0][nt][i] + acc[0][nt][i]);
+        z[i] = sigmoidf_(gi[1][nt][i] + acc[1][nt][i]);
+        hn[i] = acc[2][nt][i] + bh[nt][i];
+        n[i] = tanhf_(gi[2][nt][i] + r[i] * hn[i]);
+        if (live) h[nt][i] = (1.0f - z[i]) * n[i] + z[i] * hp[i];
+      }
+      const int u = u0 + nt * 16;
+      if (live && a.sv_r) {
+        const long s = (long)(o + b) * H + u;
+        *reinterpret_cast<bf16x4*>(a.sv_r + s) = to_bf16x4(r);
+        *reinterpret_cast<bf16x4*>(a.sv_z + s) = to_bf16x4(z);
+        *reinterpret_cast<bf16x4*>(a.sv_n + s) = to_bf16x4(n);
+        *reinterpret_cast<bf16x4*>(a.sv_hn + s) = to_bf16x4(hn);
+        *reinterpret_cast<bf16x4*>(a.sv_hprev + s) = to_bf16x4(hp);
+      }
+      *reinterpret_cast<bf16x4*>(An + u * 2) = to_bf16x4(h[nt]);
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) gi[g][nt] = gin[g][nt];
+    __syncthreads();
+  }
+  if (b < a.B) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const long s = (long)b * H + u0 + nt * 16;
+      *reinterpret_cast<f32x4*>(a.h_fin32 + s) = f32x4{h[nt][0], h[nt][1], h[nt][2], h[nt][3]};
+      *reinterpret_cast<bf16x4*>(a.h_fin_op + s) = to_bf16x4(h[nt]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: dh_{t}[b, j] = z.dh_{t+1} (carried in registers) + sum_k dGH_{t+1}[b, k] W_hh[k, j]   (k over the 3H gate
+// columns), then the gate gradients of step t from the saved activations.  The wave owns output units j in [32w, 32w+32);
+// W_hh^T rows of those units: k in [0, 2H) (r, z columns) in registers, k in [2H, 3H) (n columns) of every unit in LDS.
+// ------------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(PersistGeo<H>::NTH) void enc_bwd_persist_kernel(EncBwdPersist a, Sched sd) {
+  using G = PersistGeo<H>;
+  constexpr int KS = G::KS_H, ROWB = G::ROWB_H, ROWA = G::ROWB_3H;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sWn = smem;                 // [H][ROWB]: W_hh^T[j][2H + k]
+  char* sA = smem + G::WN_BYTES;    // [PR][ROWA]: dGH_{t+1} of the block's sequences (bf16)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int row0 = blockIdx.x * PR;
+  const int b = row0 + lr;
+  const int Tb = block_steps(sd, row0);
+  const int u0 = wave * 32 + lq * 4;
+
+  bf16x8 wreg[2][2 * KS];   // [unit tile][k step over the r|z columns]
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int ks = 0; ks < 2 * KS; ++ks)
+      wreg[nt][ks] = *reinterpret_cast<const bf16x8*>(a.WhhT + (long)(wave * 32 + nt * 16 + lr) * 3 * H + (ks * 4 + lq) * 8);
+  for (int c = tid; c < H * (H / 8); c += G::NTH) {
+    const int u = c / (H / 8), ch = c % (H / 8);
+    *reinterpret_cast<uint4*>(sWn + u * ROWB + ch * 16) = *reinterpret_cast<const uint4*>(a.WhhT + (long)u * 3 * H + 2 * H + ch * 8);
+  }
+  for (int c = tid; c < PR * ROWA / 16; c += G::NTH) reinterpret_cast<uint4*>(sA)[c] = make_uint4(0, 0, 0, 0);
+
+  struct Saved { bf16x4 r[2], z[2], n[2], hn[2], hp[2]; };
+  auto load_saved = [&](int t, Saved& s) __attribute__((always_inline)) {
+    // sequences that are over at step t read row 0 of the step (valid memory, values unused)
+    const int o = t >= 0 ? sd.off[t] : 0, Bt = t >= 0 ? sd.off[t + 1] - o : 0;
+    const long base = (long)(o + (b < Bt ? b : 0)) * H + u0;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      s.r[nt] = *reinterpret_cast<const bf16x4*>(a.sv_r + base + nt * 16);
+      s.z[nt] = *reinterpret_cast<const bf16x4*>(a.sv_z + base + nt * 16);
+      s.n[nt] = *reinterpret_cast<const bf16x4*>(a.sv_n + base + nt * 16);
+      s.hn[nt] = *reinterpret_cast<const bf16x4*>(a.sv_hn + base + nt * 16);
+      s.hp[nt] = *reinterpret_cast<const bf16x4*>(a.sv_hprev + base + nt * 16);
+    }
+  };
+  float dhc[2][4];   // direct path z.dh carried from step t+1
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dhc[nt][i] = 0.0f;
+  Saved sv;
+  if (Tb > 0) load_saved(Tb - 1, sv);
+  __syncthreads();
+
+  for (int t = Tb - 1; t >= 0; --t) {
+    Saved svn;
+    load_saved(t - 1, svn);   // prefetch the next (earlier) step; t-1 = -1 reads step 0's first row, unused
+    f32x4 acc[2];
+    acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t + 1 < Tb) {   // block-uniform: the first step has no recurrent gradient yet
+      const char* A = sA + lr * ROWA + lq * 16;
+      const char* Wn = sWn + (wave * 32 + lr) * ROWB + lq * 16;
+#pragma unroll
+      for (int ks = 0; ks < 2 * KS; ++ks) {
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(A + ks * 64);
+        acc[0] = mma16(wreg[0][ks], x, acc[0]);
+        acc[1] = mma16(wreg[1][ks], x, acc[1]);
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(A + 4 * H + ks * 64);
+        const bf16x8 n0 = *reinterpret_cast<const bf16x8*>(Wn + ks * 64);
+        const bf16x8 n1 = *reinterpret_cast<const bf16x8*>(Wn + 16 * ROWB + ks * 64);
+        acc[0] = mma16(n0, x, acc[0]);
+        acc[1] = mma16(n1, x, acc[1]);
+      }
+    }
+    const int o = sd.off[t], Bt = sd.off[t + 1] - o;
+    const int Bt1 = (t + 1 < sd.T) ? sd.off[t + 2] - sd.off[t + 1] : 0;
+    const bool live = b < Bt, first = live && b >= Bt1;   // first: step t is this sequence's last step
+    float dr[2][4], dzg[2][4], dn[2][4], dnr[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      float dh[4];
+      if (first) {
+        const f32x4 inj = *reinterpret_cast<const f32x4*>(a.dhfin + (long)b * H + u0 + nt * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dh[i] = inj[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dh[i] = dhc[nt][i] + acc[nt][i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float r = (float)sv.r[nt][i], z = (float)sv.z[nt][i], n = (float)sv.n[nt][i];
+        const float hn = (float)sv.hn[nt][i], hp = (float)sv.hp[nt][i];
+        const float d = live ? dh[i] : 0.0f;
+        dn[nt][i] = d * (1.0f - z) * (1.0f - n * n);
+        dzg[nt][i] = d * (hp - n) * z * (1.0f - z);
+        dr[nt][i] = dn[nt][i] * hn * r * (1.0f - r);
+        dnr[nt][i] = dn[nt][i] * r;
+        dhc[nt][i] = d * z;
+      }
+      if (live) {
+        const long s = (long)(o + b) * 3 * H + u0 + nt * 16;
+        *reinterpret_cast<bf16x4*>(a.dGI + s) = to_bf16x4(dr[nt]);
+        *reinterpret_cast<bf16x4*>(a.dGI + s + H) = to_bf16x4(dzg[nt]);
+        *reinterpret_cast<bf16x4*>(a.dGI + s + 2 * H) = to_bf16x4(dn[nt]);
+        *reinterpret_cast<bf16x4*>(a.dGH + s) = to_bf16x4(dr[nt]);
+        *reinterpret_cast<bf16x4*>(a.dGH + s + H) = to_bf16x4(dzg[nt]);
+        *reinterpret_cast<bf16x4*>(a.dGH + s + 2 * H) = to_bf16x4(dnr[nt]);
+      }
+    }
+    __syncthreads();   // every wave has finished reading dGH_{t+1}
+    {
+      char* An = sA + lr * ROWA;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int u = u0 + nt * 16;
+        *reinterpret_cast<bf16x4*>(An + u * 2) = to_bf16x4(dr[nt]);
+        *reinterpret_cast<bf16x4*>(An + (H + u) * 2) = to_bf16x4(dzg[nt]);
+        *reinterpret_cast<bf16x4*>(An + (2 * H + u) * 2) = to_bf16x4(dnr[nt]);
+      }
+    }
+    sv = svn;
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+bool enc_persist_supported(int H) { return H == 256; }
+
+int launch_enc_fwd_persist(const EncFwdPersist& a, const Sched& sd, int H, hipStream_t stream) {
+  PG_REQUIRE(enc_persist_supported(H), "enc_fwd_persist: hidden size %d not covered", H);
+  PG_REQUIRE(a.Whh && a.table && a.bhn && a.tok && a.h_fin32 && a.h_fin_op && a.B > 0, "enc_fwd_persist: NULL buffer");
+  using G = PersistGeo<256>;
+  PG_LAUNCH_BIG_SMEM((enc_fwd_persist_kernel<256>), dim3(cdiv(a.B, PR)), dim3(G::NTH), (size_t)G::FWD_SMEM, stream, a, sd);
+  PG_CHECK_LAUNCH();
+  return PG_OK;
+}
+
+int launch_enc_bwd_persist(const EncBwdPersist& a, const Sched& sd, int H, hipStream_t stream) {
+  PG_REQUIRE(enc_persist_supported(H), "enc_bwd_persist: hidden size %d not covered", H);
+  PG_REQUIRE(a.WhhT && a.dhfin && a.sv_r && a.dGI && a.dGH && a.B > 0, "enc_bwd_persist: NULL buffer");
+  using G = PersistGeo<256>;
+  PG_LAUNCH_BIG_SMEM((enc_bwd_persist_kernel<256>), dim3(cdiv(a.B, PR)), dim3(G::NTH), (size_t)G::BWD_SMEM, stream, a, sd);
+  PG_CHECK_LAUNCH();
+  return PG_OK;
+}

@@ -5,6 +5,9 @@
 #include "pg_gru.h"
 #include "pg_layout.h"
 #include "pg_misc.h"
+#include "pg_persist.h"
+#include <stdlib.h>
+#include <type_traits>
 
 thread_local char g_pg_err[512] = {0};
 
@@ -166,6 +169,13 @@ static inline long sum_len(const int32_t* l, int B) {
   return s;
 }
 
+// the row-resident persistent recurrence (pg_persist.h) unless the size is not covered; PG_NO_PERSIST=1 forces the per-step
+// kernels (A/B timing and a second implementation for the parity tests)
+static bool use_persistent(int H) {
+  static const bool off = getenv("PG_NO_PERSIST") && atoi(getenv("PG_NO_PERSIST")) != 0;
+  return !off && enc_persist_supported(H);
+}
+
 template <typename T> static int convert_to(const float* in, T* out, long n, hipStream_t st) {
   hipLaunchKernelGGL(convert_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, st, in, out, n);
   PG_CHECK_LAUNCH();
@@ -209,7 +219,22 @@ static int encoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
   float* scal = at<float>(ws, w.scalars);
   PG_CHECK_HIP(hipMemsetAsync(scal + SC_KL_SUM, 0, 2 * sizeof(float), st));
   float* carry = at<float>(ws, w.e_carry);
-  for (int t = 0; t < se.T; ++t) {
+  bool persist = false;
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    if (use_persistent(Hq)) {   // one launch walks every step with the recurrent weights resident on the CU
+      EncFwdPersist pa;
+      pa.Whh = at<T>(shadow, so.enc_whh); pa.table = at<float>(shadow, so.tab_enc); pa.bhn = params + po.enc_bhh + 2 * Hq;
+      pa.tok = at<int>(ws, w.enc_tok);
+      if (save) {
+        pa.sv_r = at<T>(ws, w.e_sv[0]); pa.sv_z = at<T>(ws, w.e_sv[1]); pa.sv_n = at<T>(ws, w.e_sv[2]);
+        pa.sv_hn = at<T>(ws, w.e_sv[3]); pa.sv_hprev = at<T>(ws, w.e_sv[4]);
+      }
+      pa.h_fin32 = carry; pa.h_fin_op = at<T>(ws, w.e_hfin_op); pa.B = B;
+      PG_TRY(launch_enc_fwd_persist(pa, se, Hq, st));
+      persist = true;
+    }
+  }
+  for (int t = 0; t < se.T && !persist; ++t) {
     GruFwdArgs<T> a;
     a.rows = sched_B(se, t); a.H = Hq;
     if (t > 0) { a.hprev_op = at<T>(ws, w.e_hop[(t - 1) & 1]); a.hprev32 = carry; }
@@ -228,7 +253,7 @@ static int encoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
     PG_TRY(launch_gru_fwd<T>(a, st));
   }
   // q_mu | q_logvar on the final states (each row's own last step: the carry is updated in place)
-  PG_TRY(convert_to<T>(carry, at<T>(ws, w.e_hfin_op), (long)B * Hq, st));
+  if (!persist) PG_TRY(convert_to<T>(carry, at<T>(ws, w.e_hfin_op), (long)B * Hq, st));
   GemmEpi<T> e;
   e.bias = at<float>(shadow, so.bq); e.C32 = at<float>(ws, w.e_mulv); e.ldc = 2 * Dz;
   PG_TRY(launch_gemm_nt<T>(at<T>(ws, w.e_hfin_op), Hq, at<T>(shadow, so.wq), Hq, B, 2 * Dz, Hq, e, st));
@@ -538,7 +563,19 @@ static int encoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   }
   T* dGI = at<T>(ws, w.b_dGI);
   T* dGH = at<T>(ws, w.b_dGH);
-  for (int t = se.T - 1; t >= 0; --t) {
+  bool persist = false;
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    if (use_persistent(Hq)) {
+      EncBwdPersist pa;
+      pa.WhhT = at<T>(shadow, so.enc_whhT); pa.dhfin = dhfin;
+      pa.sv_r = at<T>(ws, w.e_sv[0]); pa.sv_z = at<T>(ws, w.e_sv[1]); pa.sv_n = at<T>(ws, w.e_sv[2]);
+      pa.sv_hn = at<T>(ws, w.e_sv[3]); pa.sv_hprev = at<T>(ws, w.e_sv[4]);
+      pa.dGI = dGI; pa.dGH = dGH; pa.B = B;
+      PG_TRY(launch_enc_bwd_persist(pa, se, Hq, st));
+      persist = true;
+    }
+  }
+  for (int t = se.T - 1; t >= 0 && !persist; --t) {
     GruBwdArgs<T> a;
     a.H = Hq;
     a.rows_out = sched_B(se, t);
