@@ -27,6 +27,8 @@ int launch_gemm_nt(const T* A, long lda, const T* B, long ldb, int M, int N, int
                    hipStream_t stream);
 
 // C[M,N] (fp32, ldc) += alpha * A[R,M]^T . B[R,N]  (atomic accumulation, C must be initialised by the caller).
+// colsum_a[M] / colsum_b[N] (optional): += alpha * column sums of A / B over the R rows (bias gradients), taken from the
+// chunks the kernel stages anyway - no second pass over the operand.
 template <typename T>
 int launch_gemm_tn(const T* A, long lda, const T* B, long ldb, int M, int N, int R, float* C, long ldc, float alpha,
-                   const float* alpha_dev, hipStream_t stream);
+                   const float* alpha_dev, hipStream_t stream, float* colsum_a = nullptr, float* colsum_b = nullptr);

@@ -1,4 +1,5 @@
 // Batched GEMM kernels (NT and TN forms) on the gfx950 MFMA tile engines.
+#include <stdlib.h>
 #include "pg_gemm.h"
 #include "pg_mma.h"
 
@@ -59,26 +60,62 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_nt_kernel(const typename C
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_tn_kernel(const typename Cfg::T* __restrict__ A, long lda,
                                                                  const typename Cfg::T* __restrict__ B, long ldb, int M,
-                                                                 int N, int R, int rows_per_split, float* C, long ldc,
-                                                                 float alpha, const float* alpha_dev) {
+                                                                 int N, int R, int rows_per_split, int nsplits, float* C,
+                                                                 long ldc, float alpha, const float* alpha_dev,
+                                                                 float* colsum_a, float* colsum_b) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tiles_n = (N + Cfg::BN - 1) / Cfg::BN;
-  const int bm = blockIdx.x / tiles_n, bn = blockIdx.x % tiles_n;
+  // XCD-aware map: workgroups go round-robin over the 8 XCDs (private L2 each), so every tile of one row split is placed
+  // on the SAME XCD - the split's rows of A and B then cross the fabric once instead of once per XCD that holds a tile.
+  const int tiles_n = (N + Cfg::BN - 1) / Cfg::BN, tiles = ((M + Cfg::BM - 1) / Cfg::BM) * tiles_n;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int split = (slot / tiles) * 8 + xcd, tile = slot % tiles;
+  if (split >= nsplits) return;
+  const int bm = tile / tiles_n, bn = tile % tiles_n;
   const int m0 = bm * Cfg::BM, n0 = bn * Cfg::BN;
-  const int r0 = blockIdx.y * rows_per_split;
+  const int r0 = split * rows_per_split;
   const int r1 = min(R, r0 + rows_per_split);
   f32x16 acc[Cfg::TM][Cfg::TN];
-{
+  {
     const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
       for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = zacc;
   }
-  mma_mainloop_tn<Cfg>(acc, A, lda, m0, M, B, ldb, n0, N, r0, r1, smem);
+  // fused column sums (bias gradients): taken by the tiles that sit in the first tile column of the OTHER operand
+  const bool csa = colsum_a != nullptr && bn == 0, csb = colsum_b != nullptr && bm == 0;
+  float ca[Cfg::EPC], cb[Cfg::EPC];
+#pragma unroll
+  for (int e = 0; e < Cfg::EPC; ++e) ca[e] = cb[e] = 0.0f;
+  mma_mainloop_tn<Cfg>(acc, A, lda, m0, M, B, ldb, n0, N, r0, r1, smem, csa, csb, ca, cb);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
   if (alpha_dev) alpha *= *alpha_dev;
+  // column sums: the NTHREADS/ACH threads that staged the same columns are reduced through LDS, one atomic per column
+  float* xs = reinterpret_cast<float*>(smem);
+  if (csa) {
+    const int grp = threadIdx.x / Cfg::ACH, ch = threadIdx.x % Cfg::ACH;
+#pragma unroll
+    for (int e = 0; e < Cfg::EPC; ++e) xs[grp * Cfg::BM + ch * Cfg::EPC + e] = ca[e];
+    __syncthreads();
+    if (threadIdx.x < Cfg::BM && m0 + threadIdx.x < M) {
+      float t = 0.0f;
+      for (int g = 0; g < Cfg::NTHREADS / Cfg::ACH; ++g) t += xs[g * Cfg::BM + threadIdx.x];
+      atomicAdd(colsum_a + m0 + threadIdx.x, t * alpha);
+    }
+    __syncthreads();
+  }
+  if (csb) {
+    const int grp = threadIdx.x / Cfg::BCH, ch = threadIdx.x % Cfg::BCH;
+#pragma unroll
+    for (int e = 0; e < Cfg::EPC; ++e) xs[grp * Cfg::BN + ch * Cfg::EPC + e] = cb[e];
+    __syncthreads();
+    if (threadIdx.x < Cfg::BN && n0 + threadIdx.x < N) {
+      float t = 0.0f;
+      for (int g = 0; g < Cfg::NTHREADS / Cfg::BCH; ++g) t += xs[g * Cfg::BN + threadIdx.x];
+      atomicAdd(colsum_b + n0 + threadIdx.x, t * alpha);
+    }
+  }
 #pragma unroll
   for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
@@ -121,27 +158,41 @@ int launch_gemm_nt(const T* A, long lda, const T* B, long ldb, int M, int N, int
   return PG_OK;
 }
 
+template <class Cfg, typename T>
+static int launch_gemm_tn_cfg(const T* A, long lda, const T* B, long ldb, int M, int N, int R, float* C, long ldc, float alpha,
+                              const float* alpha_dev, int target_blocks, float* colsum_a, float* colsum_b, hipStream_t stream) {
+  static_assert(Cfg::SMEM_BYTES >= (Cfg::NTHREADS / Cfg::ACH) * Cfg::BM * 4 && Cfg::SMEM_BYTES >= (Cfg::NTHREADS / Cfg::BCH) * Cfg::BN * 4,
+                "column-sum reduction must fit the staging LDS");
+  const int tiles = cdiv(M, Cfg::BM) * cdiv(N, Cfg::BN);
+  int splits = max(1, min(cdiv(R, Cfg::BKR * 4), max(1, target_blocks / tiles)));
+  if (splits > 8) splits -= splits % 8;   // whole rounds over the 8 XCDs (see the kernel's block map)
+  int rows_per_split = cdiv(cdiv(R, splits), Cfg::BKR) * Cfg::BKR;
+  splits = cdiv(R, rows_per_split);
+  dim3 grid(8 * cdiv(splits, 8) * tiles);
+  PG_LAUNCH_BIG_SMEM(gemm_tn_kernel<Cfg>, grid, dim3(Cfg::NTHREADS), Cfg::SMEM_BYTES, stream, A, lda, B, ldb, M, N, R,
+                     rows_per_split, splits, C, ldc, alpha, alpha_dev, colsum_a, colsum_b);
+  PG_CHECK_LAUNCH();
+  return PG_OK;
+}
+
 template <typename T>
 int launch_gemm_tn(const T* A, long lda, const T* B, long ldb, int M, int N, int R, float* C, long ldc, float alpha,
-                   const float* alpha_dev, hipStream_t stream) {
+                   const float* alpha_dev, hipStream_t stream, float* colsum_a, float* colsum_b) {
   constexpr int EPC = 16 / sizeof(T);
   if (M <= 0 || N <= 0 || R <= 0) return PG_OK;
   PG_REQUIRE(lda % EPC == 0 && ldb % EPC == 0, "gemm_tn: lda/ldb must be multiples of %d", EPC);
   PG_REQUIRE(lda >= (M + EPC - 1) / EPC * EPC && ldb >= (N + EPC - 1) / EPC * EPC, "gemm_tn: rows must be padded to whole chunks");
   PG_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm_tn: operands must be 16-byte aligned");
-  using Cfg = TileTN<T, 128, 128, 32, 2, 2>;
-  const int tiles = cdiv(M, Cfg::BM) * cdiv(N, Cfg::BN);
-  int splits = max(1, min(cdiv(R, Cfg::BKR * 4), cdiv(1024, tiles)));
-  int rows_per_split = cdiv(cdiv(R, splits), Cfg::BKR) * Cfg::BKR;
-  splits = cdiv(R, rows_per_split);
-  dim3 grid(tiles, splits);
-  PG_LAUNCH_BIG_SMEM(gemm_tn_kernel<Cfg>, grid, dim3(Cfg::NTHREADS), Cfg::SMEM_BYTES, stream, A, lda, B, ldb, M, N, R,
-                     rows_per_split, C, ldc, alpha, alpha_dev);
-  PG_CHECK_LAUNCH();
-  return PG_OK;
+  static const int tn_blocks = getenv("PG_TN_BLOCKS") ? atoi(getenv("PG_TN_BLOCKS")) : 384;   // tuning aids
+  static const int tn_bkr = getenv("PG_TN_BKR") ? atoi(getenv("PG_TN_BKR")) : 64;
+  if (tn_bkr == 64)
+    return launch_gemm_tn_cfg<TileTN<T, 128, 128, 64, 2, 2>>(A, lda, B, ldb, M, N, R, C, ldc, alpha, alpha_dev, tn_blocks, colsum_a,
+                                                             colsum_b, stream);
+  return launch_gemm_tn_cfg<TileTN<T, 128, 128, 32, 2, 2>>(A, lda, B, ldb, M, N, R, C, ldc, alpha, alpha_dev, tn_blocks, colsum_a,
+                                                           colsum_b, stream);
 }
 
 template int launch_gemm_nt<float>(const float*, long, const float*, long, int, int, int, const GemmEpi<float>&, hipStream_t);
 template int launch_gemm_nt<bf16_t>(const bf16_t*, long, const bf16_t*, long, int, int, int, const GemmEpi<bf16_t>&, hipStream_t);
-template int launch_gemm_tn<float>(const float*, long, const float*, long, int, int, int, float*, long, float, const float*, hipStream_t);
-template int launch_gemm_tn<bf16_t>(const bf16_t*, long, const bf16_t*, long, int, int, int, float*, long, float, const float*, hipStream_t);
+template int launch_gemm_tn<float>(const float*, long, const float*, long, int, int, int, float*, long, float, const float*, hipStream_t, float*, float*);
+template int launch_gemm_tn<bf16_t>(const bf16_t*, long, const bf16_t*, long, int, int, int, float*, long, float, const float*, hipStream_t, float*, float*);

@@ -381,11 +381,26 @@ template <> struct TnFrag<float> {
   }
 };
 
+// fp32 sum of the EPC elements of one staged 16-byte chunk into cs[] (fused column sums of the TN engine)
+template <typename T> __device__ __forceinline__ void chunk_accumulate(const uint4& v, float (&cs)[16 / sizeof(T)]);
+template <> __device__ __forceinline__ void chunk_accumulate<bf16_t>(const uint4& v, float (&cs)[8]) {
+  const bf16x8 x = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] += (float)x[e];
+}
+template <> __device__ __forceinline__ void chunk_accumulate<float>(const uint4& v, float (&cs)[4]) {
+  cs[0] += __uint_as_float(v.x); cs[1] += __uint_as_float(v.y); cs[2] += __uint_as_float(v.z); cs[3] += __uint_as_float(v.w);
+}
+
 // acc += A[r0:r1, m0:m0+BM]^T B[r0:r1, n0:n0+BN].  Columns >= Mtot / Ntot and rows >= r1 read as zero.
+// csa / csb (block-uniform): also sum this thread's staged chunks of A / B over the rows into ca / cb - the thread always
+// stages the same EPC columns (tid % ACH resp. tid % BCH), so the caller gets the operand's column sums for free.
 template <class Cfg>
 __device__ __forceinline__ void mma_mainloop_tn(f32x16 (&acc)[Cfg::TM][Cfg::TN], const typename Cfg::T* __restrict__ A, long lda,
                                                 int m0, int Mtot, const typename Cfg::T* __restrict__ B, long ldb, int n0,
-                                                int Ntot, int r0, int r1, char* smem) {
+                                                int Ntot, int r0, int r1, char* smem, bool csa, bool csb,
+                                                float (&ca)[Cfg::EPC], float (&cb)[Cfg::EPC]) {
+  static_assert(Cfg::NTHREADS % Cfg::ACH == 0 && Cfg::NTHREADS % Cfg::BCH == 0, "a thread must keep its columns across chunks");
   using T = typename Cfg::T;
   constexpr int NT = Cfg::NTHREADS, EPC = Cfg::EPC;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -417,11 +432,13 @@ __device__ __forceinline__ void mma_mainloop_tn(f32x16 (&acc)[Cfg::TM][Cfg::TN],
     for (int i = 0; i < Cfg::A_IT; ++i) {
       int id = tid + i * NT, kr = id / Cfg::ACH, c = id % Cfg::ACH;
       if (id < Cfg::BKR * Cfg::ACH) *reinterpret_cast<uint4*>(sa + kr * Cfg::ROWA + c * 16) = ra[i];
+      if (csa && id < Cfg::BKR * Cfg::ACH) chunk_accumulate<T>(ra[i], ca);
     }
 #pragma unroll
     for (int i = 0; i < Cfg::B_IT; ++i) {
       int id = tid + i * NT, kr = id / Cfg::BCH, c = id % Cfg::BCH;
       if (id < Cfg::BKR * Cfg::BCH) *reinterpret_cast<uint4*>(sb + kr * Cfg::ROWBB + c * 16) = rb[i];
+      if (csb && id < Cfg::BKR * Cfg::BCH) chunk_accumulate<T>(rb[i], cb);
     }
   };
   auto compute = [&](int buf) __attribute__((always_inline)) {

@@ -415,8 +415,7 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   T* dlog = at<T>(ws, w.d_dlogits);
   const T* top = at<T>(ws, w.d_hseq[L - 1]);
   // decoder_fc
-  PG_TRY(launch_gemm_tn<T>(dlog, Vp, top, Hd, V, Hd, (int)Nd, grads + po.fc_w, Hd, 1.0f, s_ce, st));
-  PG_TRY(colsum<T>(dlog, Nd, V, Vp, grads + po.fc_b, 1.0f, s_ce, st));
+  PG_TRY(launch_gemm_tn<T>(dlog, Vp, top, Hd, V, Hd, (int)Nd, grads + po.fc_w, Hd, 1.0f, s_ce, st, grads + po.fc_b));
   float* dout = at<float>(ws, w.b_dout);
   {
     GemmEpi<T> e;
@@ -472,13 +471,13 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
     T* dGI = at<T>(ws, w.b_dGI_l[l]);
     T* dGH = at<T>(ws, w.b_dGH_l[l]);
     // weight / bias gradients of the layer (batched over all packed rows)
+    // weight gradients of the layer, batched over all packed rows; the bias gradients (column sums of dGH / dGI) ride along
     PG_TRY(launch_gemm_tn<T>(dGH, 3 * Hd, at<T>(ws, w.d_sv[l][4]), Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_whh[l], Hd, 1.0f,
-                             nullptr, st));
-    PG_TRY(colsum<T>(dGH, Nd, 3 * Hd, 3 * Hd, grads + po.dec_bhh[l], 1.0f, nullptr, st));
-    PG_TRY(colsum<T>(dGI, Nd, 3 * Hd, 3 * Hd, grads + po.dec_bih[l], 1.0f, nullptr, st));
+                             nullptr, st, grads + po.dec_bhh[l]));
     if (l > 0) {
       const T* X = drop ? at<T>(ws, w.d_hdrop[l - 1]) : at<T>(ws, w.d_hseq[l - 1]);
-      PG_TRY(launch_gemm_tn<T>(dGI, 3 * Hd, X, Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_wih[l], Hd, 1.0f, nullptr, st));
+      PG_TRY(launch_gemm_tn<T>(dGI, 3 * Hd, X, Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_wih[l], Hd, 1.0f, nullptr, st,
+                               grads + po.dec_bih[l]));
     } else {
       // layer 0 input = [x_emb[token] ; z]: token half through the gather table, z half per sequence
       T* oh = at<T>(ws, w.b_onehot);
@@ -486,7 +485,8 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
       hipLaunchKernelGGL(onehot_kernel<T>, dim3(ew_blocks(Nd * Vp)), dim3(256), 0, st, at<int>(ws, w.dec_tok), Nd, Vp, oh);
       PG_CHECK_LAUNCH();
       PG_CHECK_HIP(hipMemsetAsync(dT, 0, (size_t)Vp * 3 * Hd * 4, st));
-      PG_TRY(launch_gemm_tn<T>(oh, Vp, dGI, 3 * Hd, Vp, 3 * Hd, (int)Nd, dT, 3 * Hd, 1.0f, nullptr, st));
+      PG_TRY(launch_gemm_tn<T>(oh, Vp, dGI, 3 * Hd, Vp, 3 * Hd, (int)Nd, dT, 3 * Hd, 1.0f, nullptr, st, nullptr,
+                               grads + po.dec_bih[0]));
       // d x_emb[v,e] += sum_g dT[v,g] W_ih0[g,e] ; d W_ih0[g,e] += sum_v dT[v,g] x_emb[v,e]
       PG_TRY(small_gemm(dT, 3 * Hd, 1, params + po.dec_wih[0], E + Dz, 1, V, E, 3 * Hd, grads + po.x_emb, E, d->pad, st));
       PG_TRY(small_gemm(dT, 1, 3 * Hd, params + po.x_emb, E, 1, 3 * Hd, E, V, grads + po.dec_wih[0], E + Dz, -1, st));
@@ -505,8 +505,7 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   // decoder_lat: h0 = W z + b feeds every layer
   T* dh0_op = at<T>(ws, w.b_dh0_op);
   PG_TRY(convert_to<T>(dh0, dh0_op, (long)B * Hd, st));
-  PG_TRY(launch_gemm_tn<T>(dh0_op, Hd, at<T>(ws, w.d_zop), Dz, Hd, Dz, B, grads + po.lat_w, Dz, 1.0f, nullptr, st));
-  PG_TRY(colsum<T>(dh0_op, B, Hd, Hd, grads + po.lat_b, 1.0f, nullptr, st));
+  PG_TRY(launch_gemm_tn<T>(dh0_op, Hd, at<T>(ws, w.d_zop), Dz, Hd, Dz, B, grads + po.lat_w, Dz, 1.0f, nullptr, st, grads + po.lat_b));
   {
     GemmEpi<T> e;
     e.C32 = dz; e.ldc = Dz; e.accumulate = 1;
@@ -551,10 +550,8 @@ static int encoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
                      at<float>(ws, w.e_eps), dz, scal, B, Dz, dq, dq_op);
   PG_CHECK_LAUNCH();
   const T* hfin = at<T>(ws, w.e_hfin_op);
-  PG_TRY(launch_gemm_tn<T>(dq_op, 2 * Dz, hfin, Hq, Dz, Hq, B, grads + po.qmu_w, Hq, 1.0f, nullptr, st));
-  PG_TRY(launch_gemm_tn<T>(dq_op + Dz, 2 * Dz, hfin, Hq, Dz, Hq, B, grads + po.qlv_w, Hq, 1.0f, nullptr, st));
-  PG_TRY(colsum<T>(dq_op, B, Dz, 2 * Dz, grads + po.qmu_b, 1.0f, nullptr, st));
-  PG_TRY(colsum<T>(dq_op + Dz, B, Dz, 2 * Dz, grads + po.qlv_b, 1.0f, nullptr, st));
+  PG_TRY(launch_gemm_tn<T>(dq_op, 2 * Dz, hfin, Hq, Dz, Hq, B, grads + po.qmu_w, Hq, 1.0f, nullptr, st, grads + po.qmu_b));
+  PG_TRY(launch_gemm_tn<T>(dq_op + Dz, 2 * Dz, hfin, Hq, Dz, Hq, B, grads + po.qlv_w, Hq, 1.0f, nullptr, st, grads + po.qlv_b));
   float* dhfin = at<float>(ws, w.b_dhfin);
   {
     GemmEpi<T> e;
@@ -591,15 +588,14 @@ static int encoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
     a.dhz_out = at<float>(ws, w.b_dhz[t & 1]);
     PG_TRY(launch_gru_bwd<T>(a, st));
   }
-  PG_TRY(launch_gemm_tn<T>(dGH, 3 * Hq, at<T>(ws, w.e_sv[4]), Hq, 3 * Hq, Hq, (int)Ne, grads + po.enc_whh, Hq, 1.0f, nullptr, st));
-  PG_TRY(colsum<T>(dGH, Ne, 3 * Hq, 3 * Hq, grads + po.enc_bhh, 1.0f, nullptr, st));
-  PG_TRY(colsum<T>(dGI, Ne, 3 * Hq, 3 * Hq, grads + po.enc_bih, 1.0f, nullptr, st));
+  PG_TRY(launch_gemm_tn<T>(dGH, 3 * Hq, at<T>(ws, w.e_sv[4]), Hq, 3 * Hq, Hq, (int)Ne, grads + po.enc_whh, Hq, 1.0f, nullptr, st,
+                           grads + po.enc_bhh));
   T* oh = at<T>(ws, w.b_onehot);
   float* dT = at<float>(ws, w.b_dT);
   hipLaunchKernelGGL(onehot_kernel<T>, dim3(ew_blocks(Ne * Vp)), dim3(256), 0, st, at<int>(ws, w.enc_tok), Ne, Vp, oh);
   PG_CHECK_LAUNCH();
   PG_CHECK_HIP(hipMemsetAsync(dT, 0, (size_t)Vp * 3 * Hq * 4, st));
-  PG_TRY(launch_gemm_tn<T>(oh, Vp, dGI, 3 * Hq, Vp, 3 * Hq, (int)Ne, dT, 3 * Hq, 1.0f, nullptr, st));
+  PG_TRY(launch_gemm_tn<T>(oh, Vp, dGI, 3 * Hq, Vp, 3 * Hq, (int)Ne, dT, 3 * Hq, 1.0f, nullptr, st, nullptr, grads + po.enc_bih));
   PG_TRY(small_gemm(dT, 3 * Hq, 1, params + po.enc_wih, E, 1, V, E, 3 * Hq, grads + po.x_emb, E, d->pad, st));
   PG_TRY(small_gemm(dT, 1, 3 * Hq, params + po.x_emb, E, 1, 3 * Hq, E, V, grads + po.enc_wih, E, -1, st));
   return PG_OK;
