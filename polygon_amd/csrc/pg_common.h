@@ -75,11 +75,22 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t 
 // uniform in [0,1) with 24 bits
 __host__ __device__ __forceinline__ float pg_u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
-// dropout keep/scale factor for element (layer, t, global batch row, column); p = drop probability
-__device__ __forceinline__ float dropout_scale(uint64_t seed, int layer, int t, int bglob, int col, float p, float inv_keep) {
-  Philox4 r = philox4x32_10((uint32_t)col, (uint32_t)bglob, (uint32_t)t, (uint32_t)layer, (uint32_t)seed,
+// dropout keep/scale factors: ONE Philox call covers the 4 consecutive columns 4*col4 .. 4*col4+3 of
+// (layer, t, global batch row); p = drop probability.  Every kernel (forward mask, BPTT mask) goes through these two.
+__device__ __forceinline__ void dropout_scale4(uint64_t seed, int layer, int t, int bglob, int col4, float p, float inv_keep,
+                                               float (&m)[4]) {
+  Philox4 r = philox4x32_10((uint32_t)col4, (uint32_t)bglob, (uint32_t)t, (uint32_t)layer, (uint32_t)seed,
                             (uint32_t)(seed >> 32));
-  return pg_u01(r.x) >= p ? inv_keep : 0.0f;
+  m[0] = pg_u01(r.x) >= p ? inv_keep : 0.0f;
+  m[1] = pg_u01(r.y) >= p ? inv_keep : 0.0f;
+  m[2] = pg_u01(r.z) >= p ? inv_keep : 0.0f;
+  m[3] = pg_u01(r.w) >= p ? inv_keep : 0.0f;
+}
+__device__ __forceinline__ float dropout_scale(uint64_t seed, int layer, int t, int bglob, int col, float p, float inv_keep) {
+  float m[4];
+  dropout_scale4(seed, layer, t, bglob, col >> 2, p, inv_keep, m);
+  const int e = col & 3;
+  return e == 0 ? m[0] : e == 1 ? m[1] : e == 2 ? m[2] : m[3];
 }
 
 // LDS requests above 64 KiB need the per-function opt-in (once per kernel per process).

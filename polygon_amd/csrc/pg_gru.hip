@@ -346,10 +346,11 @@ __device__ __forceinline__ void gru_fwd2_body(const GruFwdArgs<T>& a, int bx, in
       Vec8<T>::store(a.sv_hn + o, hn); Vec8<T>::store(a.sv_hprev + o, hp[c]);
     }
     if (a.h_drop) {
-      float hd[8];
+      float hd[8], m0[4], m1[4];
+      dropout_scale4(a.seed, a.layer, a.t, b * a.b_mul + a.b_add, j >> 2, a.p_drop, inv_keep, m0);
+      dropout_scale4(a.seed, a.layer, a.t, b * a.b_mul + a.b_add, (j >> 2) + 1, a.p_drop, inv_keep, m1);
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        hd[i] = h[i] * dropout_scale(a.seed, a.layer, a.t, b * a.b_mul + a.b_add, j + i, a.p_drop, inv_keep);
+      for (int i = 0; i < 4; ++i) { hd[i] = h[i] * m0[i]; hd[4 + i] = h[4 + i] * m1[i]; }
       Vec8<T>::store(a.h_drop + o, hd);
     }
   }
@@ -452,13 +453,13 @@ __device__ __forceinline__ void gru_bwd2_body(const GruBwdArgs<T>& a, int bx, in
         float au[8];
         Vec8<float>::load(xt + (V2_BM + row) * V2_LD + col, au);
         const float inv_keep = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float m = a.p_drop > 0.0f
-                              ? dropout_scale(a.seed, a.layer, a.t, b * a.b_mul + a.b_add, j + i, a.p_drop, inv_keep)
-                              : 1.0f;
-          dh[c][i] += m * au[i];
+        float m0[4] = {1.0f, 1.0f, 1.0f, 1.0f}, m1[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        if (a.p_drop > 0.0f) {
+          dropout_scale4(a.seed, a.layer, a.t, b * a.b_mul + a.b_add, j >> 2, a.p_drop, inv_keep, m0);
+          dropout_scale4(a.seed, a.layer, a.t, b * a.b_mul + a.b_add, (j >> 2) + 1, a.p_drop, inv_keep, m1);
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dh[c][i] += m0[i] * au[i]; dh[c][4 + i] += m1[i] * au[4 + i]; }
       }
     }
     if (a.final_step) {

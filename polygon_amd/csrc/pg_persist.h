@@ -31,6 +31,43 @@ struct EncBwdPersist {
   int B = 0;
 };
 
+// Decoder stack (L layers, H = 512), forward with teacher forcing.  The weights of one layer no longer fit one CU, so a
+// GROUP of L * H/64 workgroups shares them: workgroup (layer l, slice c) keeps the W_hh / W_ih rows of 64 hidden units
+// stationary in its registers (4 waves x 16 units x 3 gates x K = 2H) and every group walks the time steps of its own
+// 1/NG of the batch (sequences g, g+NG, g+2NG, ... so that all groups shrink together as sequences end).  Per step a
+// workgroup needs the whole h_{l,t-1} and x = h_{l-1,t} rows of its sequences: it reads them from the hseq arrays the
+// other workgroups of the group publish (write-through stores, then one arrival on a per-(group, layer) counter) - an
+// all-gather through the memory side of the L2s, never a grid-wide barrier: layer l runs step t as soon as (l, t-1)
+// and (l-1, t) are complete, so the layers pipeline by themselves.
+struct DecFwdPersist {
+  int L = 0, B = 0, NG = 0;
+  const bf16_t* Whh[PG_MAX_LAYERS] = {};      // [3H, H]
+  const bf16_t* Wih[PG_MAX_LAYERS] = {};      // [3H, H] for l >= 1 (layer 0 takes its input through the gather table)
+  const float* bhn[PG_MAX_LAYERS] = {};       // [H]
+  const float* bias_gi[PG_MAX_LAYERS] = {};   // [3H] for l >= 1: b_ih + (b_hr | b_hz | 0)
+  const float* table = nullptr;               // layer 0: [V, 3H]
+  const int* tok = nullptr;                   // packed decoder input tokens [N]
+  const float* zproj = nullptr;               // [B, 3H]
+  const bf16_t* h0_op = nullptr;              // [B, H]
+  const float* h0_32 = nullptr;               // [B, H]
+  bf16_t* hseq[PG_MAX_LAYERS] = {};           // packed [N, H]: layer outputs (published between workgroups)
+  bf16_t* hdrop[PG_MAX_LAYERS] = {};          // packed [N, H]: dropout-masked outputs (null: no dropout / top layer)
+  float* carry[PG_MAX_LAYERS] = {};           // [B, H] fp32 state
+  bf16_t* sv[PG_MAX_LAYERS][5] = {};          // packed [N, H] r, z, n, hn, hprev (null: inference)
+  float p_drop = 0.0f;
+  uint64_t seed = 0;
+  int b_mul = 1, b_add = 0;
+  unsigned* sync = nullptr;                   // PG_PERSIST_SYNC_WORDS words, zeroed by the launcher
+  unsigned* fail = nullptr;                   // set by the launcher: process-wide sticky give-up word
+  unsigned long long* stamps = nullptr;       // development aid: wall-clock stamps of one workgroup (pg_persist_stamps)
+};
+constexpr int PG_PERSIST_SYNC_WORDS = 1040;   // counters [8 groups][PG_MAX_LAYERS] at a 16-word stride, then the give-up word
+
+bool dec_persist_supported(int H, int L, int B);
+int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t stream);
+// nonzero once a persistent kernel of this process gave up waiting on another workgroup (checked by every entry point)
+int persist_poll_failure();
+
 // true when the persistent kernels cover this hidden size (others take the per-step path)
 bool enc_persist_supported(int H);
 int launch_enc_fwd_persist(const EncFwdPersist& a, const Sched& sd, int H, hipStream_t stream);

@@ -172,8 +172,22 @@ static inline long sum_len(const int32_t* l, int B) {
 // the row-resident persistent recurrence (pg_persist.h) unless the size is not covered; PG_NO_PERSIST=1 forces the per-step
 // kernels (A/B timing and a second implementation for the parity tests)
 static bool use_persistent(int H) {
-  static const bool off = getenv("PG_NO_PERSIST") && atoi(getenv("PG_NO_PERSIST")) != 0;
+  static const bool off = getenv("PG_NO_PERSIST") && (atoi(getenv("PG_NO_PERSIST")) & 1) != 0;   // bit 0 encoder, bit 1 decoder
   return !off && enc_persist_supported(H);
+}
+
+// a persistent kernel of an earlier call gave up waiting for a peer workgroup (it was not co-resident): everything computed
+// since is suspect, so every later call fails loudly instead of returning numbers
+static int check_persist() {
+  PG_REQUIRE(persist_poll_failure() == 0,
+             "a persistent recurrence kernel timed out waiting for its peer workgroups (GPU shared or partially available?); "
+             "set PG_NO_PERSIST=3 to use the per-step kernels");
+  return PG_OK;
+}
+
+static bool use_persistent_dec(int H, int L, int B) {
+  static const bool off = getenv("PG_NO_PERSIST") && (atoi(getenv("PG_NO_PERSIST")) & 2) != 0;
+  return !off && dec_persist_supported(H, L, B);
 }
 
 template <typename T> static int convert_to(const float* in, T* out, long n, hipStream_t st) {
@@ -271,6 +285,7 @@ extern "C" int pg_encoder_fwd(const pg_dims* d, int dtype, const float* params, 
                               const pg_dp* dp, int save_for_backward, float* z, float* mu, float* logvar, float* kl,
                               void* stream) {
   PG_TRY(check_dims(d, dtype));
+  PG_TRY(check_persist());
   PG_REQUIRE(params && shadow && ws && d_tokens && z, "pg_encoder_fwd: NULL buffer");
   return dtype == PG_BF16
              ? encoder_fwd_t<bf16_t>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, d_tokens, h_lengths, eps, dp,
@@ -316,15 +331,43 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
     PG_TRY(launch_gemm_nt<T>(z_op, Dz, at<T>(shadow, so.lat_w), Dz, B, Hd, Dz, e, st));
   }
   const bool drop = p_drop > 0.0f;
-  for (int l = 0; l < L; ++l)
+  const bool persist_dec = std::is_same<T, bf16_t>::value && use_persistent_dec(Hd, L, B);
+  for (int l = 0; l < L && !persist_dec; ++l)   // (the persistent kernel reads h0 itself at step 0)
     PG_CHECK_HIP(hipMemcpyAsync(at<float>(ws, w.d_carry[l]), at<float>(ws, w.d_h0_32), (size_t)B * Hd * 4,
                                 hipMemcpyDeviceToDevice, st));
   // Wavefront over the (layer, t) grid: cell (l, t) needs (l, t-1) and (l-1, t), so all cells of one anti-diagonal
   // are independent and run in ONE launch; layers >= 1 take their input projection fused (x = output of the layer
   // below at the same step).  T + L - 1 sequential launches instead of T * L.
-  const int pslot = prof_begin(0, st);
+  bool persist = false;
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    if (use_persistent_dec(Hd, L, B)) {   // ONE launch: weights stationary per workgroup, layers pipelined through counters
+      static_assert(PG_PERSIST_SYNC_WORDS == 1040, "TrainWs::sync is sized for 1040 words");
+      DecFwdPersist pa;
+      pa.L = L; pa.B = B;
+      for (int l = 0; l < L; ++l) {
+        pa.Whh[l] = at<T>(shadow, so.whh[l]);
+        pa.bhn[l] = params + po.dec_bhh[l] + 2 * Hd;
+        if (l > 0) { pa.Wih[l] = at<T>(shadow, so.wih[l]); pa.bias_gi[l] = at<float>(shadow, so.bias_gi[l]); }
+        pa.hseq[l] = at<T>(ws, w.d_hseq[l]);
+        pa.hdrop[l] = (drop && l < L - 1) ? at<T>(ws, w.d_hdrop[l]) : nullptr;
+        pa.carry[l] = at<float>(ws, w.d_carry[l]);
+        if (save) for (int i = 0; i < 5; ++i) pa.sv[l][i] = at<T>(ws, w.d_sv[l][i]);
+      }
+      pa.table = at<float>(shadow, so.tab_dec); pa.tok = at<int>(ws, w.dec_tok); pa.zproj = at<float>(ws, w.d_zproj);
+      pa.h0_op = at<T>(ws, w.d_h0_op); pa.h0_32 = at<float>(ws, w.d_h0_32);
+      pa.p_drop = p_drop; pa.seed = seed; pa.b_mul = b_mul; pa.b_add = b_add;
+      pa.sync = at<unsigned>(ws, w.sync);
+      const int pslot = prof_begin(0, st);
+      PG_TRY(launch_dec_fwd_persist(pa, sd, Hd, st));
+      double pflop = 0.0;
+      for (int t = 0; t < sd.T; ++t) pflop += 2.0 * sched_B(sd, t) * 3.0 * Hd * (L * Hd + (L - 1) * Hd);
+      prof_end(0, pslot, st, 1, pflop);
+      persist = true;
+    }
+  }
+  const int pslot = persist ? -1 : prof_begin(0, st);
   double pflop = 0.0;
-  for (int dgi = 0; dgi < sd.T + L - 1; ++dgi) {
+  for (int dgi = 0; dgi < sd.T + L - 1 && !persist; ++dgi) {
     GruFwdDiag<T> dg;
     for (int l = 0; l < L; ++l) {
       const int t = dgi - l;
@@ -384,6 +427,7 @@ extern "C" int pg_decoder_fwd(const pg_dims* d, int dtype, const float* params, 
                               const pg_dp* dp, float p_drop, uint64_t seed, int all_steps, int save_for_backward,
                               float* recon, float** logits_packed, void* stream) {
   PG_TRY(check_dims(d, dtype));
+  PG_TRY(check_persist());
   PG_REQUIRE(params && shadow && ws && d_tokens && z, "pg_decoder_fwd: NULL buffer");
   return dtype == PG_BF16
              ? decoder_fwd_t<bf16_t>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, d_tokens, h_lengths, z, dp, p_drop, seed,
@@ -518,6 +562,7 @@ extern "C" int pg_decoder_bwd(const pg_dims* d, int dtype, const float* params, 
                               int B, int Tmax, const int32_t* h_lengths, const pg_dp* dp, float p_drop, uint64_t seed,
                               int all_steps, float g_host, const float* g_dev, float* grads, float* dz, void* stream) {
   PG_TRY(check_dims(d, dtype));
+  PG_TRY(check_persist());
   PG_REQUIRE(params && shadow && ws && grads && dz, "pg_decoder_bwd: NULL buffer");
   return dtype == PG_BF16 ? decoder_bwd_t<bf16_t>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, h_lengths, dp, p_drop, seed,
                                                   all_steps, g_host, g_dev, grads, dz, (hipStream_t)stream)
@@ -605,6 +650,7 @@ extern "C" int pg_encoder_bwd(const pg_dims* d, int dtype, const float* params, 
                               int B, int Tmax, const int32_t* h_lengths, const pg_dp* dp, const float* dz, float g_host,
                               const float* g_dev, float* grads, void* stream) {
   PG_TRY(check_dims(d, dtype));
+  PG_TRY(check_persist());
   PG_REQUIRE(params && shadow && ws && grads, "pg_encoder_bwd: NULL buffer");
   return dtype == PG_BF16 ? encoder_bwd_t<bf16_t>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, h_lengths, dp, dz, g_host, g_dev,
                                                   grads, (hipStream_t)stream)
