@@ -132,6 +132,11 @@ PG_API int pg_bench_gru(int dtype, int which, int rows, int H, void* ws, size_t 
 PG_API int pg_profile_enable(int on);
 PG_API int pg_profile_read(int which, double* total_ms, long* launches, double* flop, int* segments);
 
+/* Test / A-B hook (no reference counterpart): the recurrences run as persistent kernels where the shape is covered
+ * (bf16, Hq = 256, Hd = 512); mask bits force the per-step kernels instead: 1 encoder, 2 decoder forward, 4 decoder BPTT.
+ * mask < 0 only queries.  Returns the previous mask.  The environment variable PG_NO_PERSIST sets the initial mask. */
+PG_API int pg_persist_disable(int mask);
+
 #ifdef __cplusplus
 }
 #endif

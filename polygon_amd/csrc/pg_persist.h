@@ -12,6 +12,14 @@
 #include "pg_common.h"
 #include "pg_layout.h"
 
+#ifndef PG_TRY
+#define PG_TRY(expr)            \
+  do {                          \
+    int _s = (expr);            \
+    if (_s != PG_OK) return _s; \
+  } while (0)
+#endif
+
 struct EncFwdPersist {
   const bf16_t* Whh = nullptr;     // [3H, H] (gate-major rows r|z|n, K contiguous)
   const float* table = nullptr;    // [V, 3H]: x_emb[v].W_ih^T + b_ih + (b_hr | b_hz | 0)
@@ -63,8 +71,34 @@ struct DecFwdPersist {
 };
 constexpr int PG_PERSIST_SYNC_WORDS = 1040;   // counters [8 groups][PG_MAX_LAYERS] at a 16-word stride, then the give-up word
 
+// Decoder stack, backward (BPTT): the same grouping, workgroup (layer l, slice c) keeps the rows of W_hh_l^T and
+// W_ih_{l+1}^T that produce dh of its 64 units.  It consumes dGH_{l,t+1} (own layer) and dGI_{l+1,t} (layer above) as
+// published by the other workgroups and publishes dGI_{l,t} / dGH_{l,t}; see pg_persist_bwd.hip.
+struct DecBwdPersist {
+  int L = 0, B = 0, NG = 0;
+  const bf16_t* WhhT[PG_MAX_LAYERS] = {};     // [H, 3H]
+  const bf16_t* WihT[PG_MAX_LAYERS] = {};     // [H, 3H] of layer l >= 1 (read by the workgroups of layer l-1)
+  const float* dout = nullptr;                // packed [N, H]: gradient of the top layer's outputs (vocab projection)
+  const bf16_t* sv[PG_MAX_LAYERS][5] = {};    // packed [N, H] r, z, n, hn, hprev saved by the forward pass
+  bf16_t* dGI[PG_MAX_LAYERS] = {};            // packed [N, 3H] (published)
+  bf16_t* dGH[PG_MAX_LAYERS] = {};            // packed [N, 3H] (published)
+  float* carry[PG_MAX_LAYERS] = {};           // [B, H] z.dh carried to the previous step
+  float* dh0[PG_MAX_LAYERS] = {};             // [B, H] per-layer gradient of h0 (summed by the launcher)
+  float p_drop = 0.0f;
+  uint64_t seed = 0;
+  int b_mul = 1, b_add = 0;
+  unsigned* sync = nullptr;                   // PG_PERSIST_SYNC_WORDS words, zeroed by the launcher
+  unsigned* fail = nullptr;                   // set by the launcher
+};
+
 bool dec_persist_supported(int H, int L, int B);
 int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t stream);
+// runs the whole decoder BPTT recurrence, then dh0_32 / dh0_op [B, H] = sum over layers of the h0 gradients
+int launch_dec_bwd_persist(DecBwdPersist& a, const Sched& sd, int H, float* dh0_32, bf16_t* dh0_op, hipStream_t stream);
+// process-wide sticky give-up word of the group-persistent kernels: device address (allocated on first use) and the
+// stream-ordered copy to its pinned host mirror that persist_poll_failure() reads
+int persist_fail_words(unsigned** dev);
+int persist_fail_mirror(hipStream_t stream);
 // nonzero once a persistent kernel of this process gave up waiting on another workgroup (checked by every entry point)
 int persist_poll_failure();
 

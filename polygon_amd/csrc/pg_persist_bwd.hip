@@ -1,0 +1,372 @@
+// Group-persistent decoder recurrence, backward (BPTT); the mirror image of pg_persist_dec.hip (see pg_persist.h).
+//
+// Cell (l, t):  dh = z.dh_{t+1} (carry) + dGH_{l,t+1} . W_hh_l  +  mask_l . (dGI_{l+1,t} . W_ih_{l+1})   (top layer: + dout)
+// followed by the gate gradients from the saved activations -> dGI_{l,t}, dGH_{l,t}, carry.  Both contractions run over
+// the 3H gate columns, so a workgroup (group g, layer l, unit slice c) that owns 64 OUTPUT units keeps the matching rows of
+// W_hh_l^T and W_ih_{l+1}^T stationary: per wave 16 units x (48 + 32) K-steps of MFMA fragments in registers (320 VGPRs),
+// the last 16 K-steps of W_ih_{l+1}^T (the n-gate columns) of the slice in LDS (65 KB) - the budget of the forward kernel.
+//
+// Activations are 3x wider than in the forward pass (a row is [dGH | dGI_up] = 6 KB), so a 16-row tile is streamed in six
+// 16-KB PARTS (16 rows x 512 gate columns, one LDS-DMA wave instruction per row) through a ring of NSLOT slots; part q+D+1
+// is issued when part q starts, every wave waits with a COUNTED vmcnt for its own four DMA instructions of part q, and one
+// workgroup barrier per part publishes them (and proves that the slot about to be overwritten is no longer read).
+//
+// Inter-workgroup protocol: exactly the forward kernel's (write-through stores, vmcnt drain, barrier, one agent-scope
+// counter increment per workgroup and step; consumers poll, acquire-fence, and read published rows with sc1 loads only).
+// Layer l, step t waits for (l, t+1) and (l+1, t): the layers pipeline top-down by themselves.
+#include <hip/hip_runtime.h>
+#include "pg_mma.h"
+#include "pg_persist.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+namespace {
+
+constexpr int SYNC_STRIDE = 16;
+constexpr int SYNC_ERR = PG_MAX_LAYERS * 8 * SYNC_STRIDE;
+static_assert(SYNC_ERR + 1 <= PG_PERSIST_SYNC_WORDS, "sync block too small");
+constexpr unsigned SPIN_LIMIT = 1u << 21;
+constexpr int AUX_SC1 = 16;
+constexpr int PART_BYTES = 16 * 1024;   // 16 rows x 512 bf16
+
+__device__ __forceinline__ f32x4 mma16(const bf16x8& w, const bf16x8& x, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x4 to_bf16x4(const float (&v)[4]) {
+  bf16x4 o;
+  o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+  return o;
+}
+__device__ __forceinline__ void store_sc1_b64(__amdgpu_buffer_rsrc_t r, unsigned byte_off, const bf16x4& v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)byte_off, 0, AUX_SC1);
+}
+
+__device__ __forceinline__ bool wait_ge(unsigned* p, unsigned target, unsigned* err, unsigned* sticky) {
+  for (unsigned spins = 0;; ++spins) {
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+    if ((spins & 63u) == 63u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+    if (spins > SPIN_LIMIT) {
+      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// every wave issues 4 LDS-DMA instructions per part; `younger` = parts issued after the one that must have landed.
+// Counting fewer outstanding operations than there are (the epilogue's own loads and stores are not counted) only makes
+// the wait stricter: vector memory operations of one wave complete in issue order.
+__device__ __forceinline__ void wait_parts(int younger) {
+  switch (younger) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+  }
+}
+
+template <int H, bool TOP> struct BwdGeo {
+  static constexpr int KS = 3 * H / 32;          // MFMA K steps over the 3H gate columns
+  static constexpr int KSP = 16;                 // K steps per part
+  static constexpr int KS_REG_UP = 2 * H / 32;   // upper-layer K steps held in registers (r, z columns); the rest in LDS
+  static constexpr int NCU = H / 64;
+  static constexpr int ROWW = H * 2 + 16;        // LDS row of the n-gate columns of W_ih_up^T (padded)
+  static constexpr int WN_BYTES = TOP ? 0 : 64 * ROWW;
+  static constexpr int NSLOT = TOP ? 8 : 5;
+  static constexpr int D = NSLOT - 2;            // parts in flight behind the one being consumed
+  static constexpr int SMEM = WN_BYTES + NSLOT * PART_BYTES + 16;
+};
+
+template <int H, bool TOP>
+__device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched& sd, int g, int l, int c, char* smem) {
+  using G = BwdGeo<H, TOP>;
+  constexpr int NCU = G::NCU, ROWW = G::ROWW, NSLOT = G::NSLOT, D = G::D;
+  static_assert(H == 512, "one LDS-DMA instruction (64 lanes x 16 B) must cover exactly 512 gate columns of one row");
+  static_assert(D <= 6, "wait_parts covers at most 6 parts in flight");
+  char* sWn = smem;
+  char* sR = smem + G::WN_BYTES;
+  volatile unsigned* sFlag = reinterpret_cast<volatile unsigned*>(smem + G::WN_BYTES + NSLOT * PART_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4, hi = lr >> 2;
+  const int NG = a.NG;
+  const int uw = c * 64 + wave * 16;
+  const int u0 = uw + lq * 4;
+  int Tg = 0;
+  while (Tg < sd.T && sd.off[Tg + 1] - sd.off[Tg] > g) ++Tg;
+  if (Tg == 0) return;   // no sequence of this group (B <= g): nothing to do, nobody waits for this workgroup's counters
+
+  // ---- stationary weights
+  const bf16_t* WhhT = a.WhhT[l];
+  bf16x8 wh[G::KS];
+#pragma unroll
+  for (int ks = 0; ks < G::KS; ++ks)
+    wh[ks] = *reinterpret_cast<const bf16x8*>(WhhT + (long)(uw + lr) * 3 * H + (ks * 4 + lq) * 8);
+  bf16x8 wu[TOP ? 1 : G::KS_REG_UP];
+  if constexpr (!TOP) {
+    const bf16_t* WihT = a.WihT[l + 1];
+#pragma unroll
+    for (int ks = 0; ks < G::KS_REG_UP; ++ks)
+      wu[ks] = *reinterpret_cast<const bf16x8*>(WihT + (long)(uw + lr) * 3 * H + (ks * 4 + lq) * 8);
+    for (int id = tid; id < 64 * (H / 8); id += 256) {
+      const int u = id / (H / 8), ch = id % (H / 8);
+      *reinterpret_cast<uint4*>(sWn + u * ROWW + ch * 16) =
+          *reinterpret_cast<const uint4*>(WihT + (long)(c * 64 + u) * 3 * H + 2 * H + ch * 8);
+    }
+  }
+  const float inv_keep = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+  const bool drop = !TOP && a.p_drop > 0.0f;
+  bf16_t* dGI = a.dGI[l];
+  bf16_t* dGH = a.dGH[l];
+  const bf16_t* dGIup = TOP ? nullptr : a.dGI[l + 1];
+  float* carry = a.carry[l];
+  unsigned* cnt_own = a.sync + (g * PG_MAX_LAYERS + l) * SYNC_STRIDE;
+  unsigned* cnt_up = a.sync + (g * PG_MAX_LAYERS + (TOP ? l : l + 1)) * SYNC_STRIDE;
+  unsigned* err = a.sync + SYNC_ERR;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  __syncthreads();
+
+  for (int s = 0; s <= Tg; ++s) {
+    const int t = Tg - 1 - s;                      // t = -1: the gradient of h0
+    const bool has_own = s > 0;                    // step t+1 of this group exists
+    const bool has_up = !TOP && t >= 0;
+    // ---- wait for dGH_{l,t+1} (own layer) and dGI_{l+1,t} (layer above)
+    if (tid == 0) {
+      bool ok = wait_ge(cnt_own, (unsigned)(NCU * s), err, a.fail);
+      if (has_up && ok) ok = wait_ge(cnt_up, (unsigned)(NCU * (s + 1)), err, a.fail);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      *sFlag = ok ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*sFlag == 0u) return;   // block-uniform: somebody gave up
+    const int tt = t >= 0 ? t : 0;
+    const int o = sd.off[tt], Bt = sd.off[tt + 1] - o;             // rows of this step (t = -1: those of step 0)
+    const int o1 = t >= 0 ? sd.off[t + 1] : 0;                      // rows that carry a recurrent gradient: step t+1
+    const int Bt1 = !has_own ? 0 : (t >= 0 ? sd.off[t + 2] - o1 : Bt);
+    const int nlive = (Bt - g + NG - 1) / NG;
+    const int ntile = (nlive + 15) >> 4;
+    const int Pt = (has_own ? 3 : 0) + (has_up ? 3 : 0);           // parts per tile
+    const int nparts = ntile * Pt;
+    const bf16_t* own_base = dGH + (long)o1 * 3 * H;
+    const bf16_t* up_base = TOP ? nullptr : dGIup + (long)o * 3 * H;
+    const __amdgpu_buffer_rsrc_t r_dGI = pg_make_rsrc(dGI + (long)o * 3 * H);
+    const __amdgpu_buffer_rsrc_t r_dGH = pg_make_rsrc(dGH + (long)o * 3 * H);
+
+    // flattened part sequence of the step: tile-major, own parts before upper parts
+    int qi = 0, ji = 0, pi = 0, si = 0;            // next part to issue: index, tile, part in tile, slot
+    auto issue = [&]() __attribute__((always_inline)) {
+      if (qi < nparts) {                           // block-uniform
+        const bool own = has_own && pi < 3;
+        const int sub = own ? pi : pi - (has_own ? 3 : 0);
+        const bf16_t* base = (own ? own_base : up_base) + sub * 512;
+        const int lim = own ? Bt1 : Bt;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = wave * 4 + i;
+          const int b = g + NG * (16 * ji + row);
+          const int bs = b < lim ? b : g;          // finished sequences re-read a valid row; their columns are masked
+          const bf16_t* src = base + (long)bs * 3 * H + ((lane ^ row) * 8);
+          char* dst = sR + si * PART_BYTES + row * 1024;
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, AUX_SC1);
+        }
+      }
+      ++qi;
+      if (++pi == Pt) { pi = 0; ++ji; }
+      if (++si == NSLOT) si = 0;
+    };
+    if (nparts > 0) {
+#pragma unroll 1
+      for (int i = 0; i <= D; ++i) issue();
+    }
+    int qc = 0, sc = 0;                            // part being consumed, its slot
+    // one part: wait for its DMAs, publish them, refill the slot freed by the previous part, 16 K-steps
+    auto part_begin = [&]() __attribute__((always_inline)) -> const char* {
+      const int younger = nparts - 1 - qc;
+      wait_parts(younger < D ? younger : D);
+      // a bare s_barrier: __syncthreads() carries a workgroup release fence = vmcnt(0), which would drain the very DMAs
+      // this pipeline keeps in flight.  Nothing but the DMA'd slot is communicated here (the wave's own LDS reads of the
+      // previous part were consumed by its MFMAs), so the counted wait above is the only ordering needed.
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue();
+      const char* A = sR + sc * PART_BYTES + lr * 1024 + ((lq ^ lr) & 3) * 16;
+      ++qc;
+      if (++sc == NSLOT) sc = 0;
+      return A;
+    };
+
+    for (int j = 0; j < ntile; ++j) {
+      const int b = g + NG * (16 * j + lr);
+      const bool live = b < Bt, live1 = b < Bt1;
+      const int bs = live ? b : g;
+      // epilogue inputs of this lane's sequence, fetched under the tile's MFMAs
+      f32x4 cr = f32x4{0.f, 0.f, 0.f, 0.f}, dtop = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x4 svr, svz, svn, svhn, svhp;
+      if (has_own) cr = *reinterpret_cast<const f32x4*>(carry + (long)bs * H + u0);
+      if (t >= 0) {
+        const long sidx = (long)(o + bs) * H + u0;
+        if constexpr (TOP) dtop = *reinterpret_cast<const f32x4*>(a.dout + sidx);
+        svr = *reinterpret_cast<const bf16x4*>(a.sv[l][0] + sidx);
+        svz = *reinterpret_cast<const bf16x4*>(a.sv[l][1] + sidx);
+        svn = *reinterpret_cast<const bf16x4*>(a.sv[l][2] + sidx);
+        svhn = *reinterpret_cast<const bf16x4*>(a.sv[l][3] + sidx);
+        svhp = *reinterpret_cast<const bf16x4*>(a.sv[l][4] + sidx);
+      }
+      f32x4 ah[2], au[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { ah[i] = f32x4{0.f, 0.f, 0.f, 0.f}; au[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      if (has_own) {   // block-uniform
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const char* A = part_begin();
+          bf16x8 xc = *reinterpret_cast<const bf16x8*>(A + ((0 ^ hi) << 6)), xn = xc;
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) {
+            if (ks + 1 < 16) xn = *reinterpret_cast<const bf16x8*>(A + (((ks + 1) ^ hi) << 6));
+            ah[ks & 1] = mma16(wh[p * 16 + ks], xc, ah[ks & 1]);
+            xc = xn;
+          }
+        }
+      }
+      if constexpr (!TOP) {
+        if (has_up) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const char* A = part_begin();
+            bf16x8 xc = *reinterpret_cast<const bf16x8*>(A + ((0 ^ hi) << 6)), xn = xc;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+              if (ks + 1 < 16) xn = *reinterpret_cast<const bf16x8*>(A + (((ks + 1) ^ hi) << 6));
+              au[ks & 1] = mma16(wu[p * 16 + ks], xc, au[ks & 1]);
+              xc = xn;
+            }
+          }
+          {
+            const char* A = part_begin();
+            const char* Wn = sWn + (wave * 16 + lr) * ROWW + lq * 16;
+            bf16x8 xc = *reinterpret_cast<const bf16x8*>(A + ((0 ^ hi) << 6)), xn = xc;
+            bf16x8 wc = *reinterpret_cast<const bf16x8*>(Wn), wn = wc;
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+              if (ks + 1 < 16) {
+                xn = *reinterpret_cast<const bf16x8*>(A + (((ks + 1) ^ hi) << 6));
+                wn = *reinterpret_cast<const bf16x8*>(Wn + (ks + 1) * 64);
+              }
+              au[ks & 1] = mma16(wc, xc, au[ks & 1]);
+              xc = xn; wc = wn;
+            }
+          }
+        }
+      }
+      // ---- epilogue on 4 units of sequence b
+      float dh[4];
+      float m[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+      if (drop && t >= 0) dropout_scale4(a.seed, l, t, b * a.b_mul + a.b_add, u0 >> 2, a.p_drop, inv_keep, m);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float d = live1 ? cr[e] + ah[0][e] + ah[1][e] : 0.0f;
+        if constexpr (TOP) d += dtop[e];
+        else d += m[e] * (au[0][e] + au[1][e]);
+        dh[e] = d;
+      }
+      if (t < 0) {
+        if (live) *reinterpret_cast<f32x4*>(a.dh0[l] + (long)b * H + u0) = f32x4{dh[0], dh[1], dh[2], dh[3]};
+        continue;
+      }
+      if (live) {
+        float dr[4], dz[4], dn[4], dnr[4], dhz[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float r = (float)svr[e], z = (float)svz[e], n = (float)svn[e], hn = (float)svhn[e], hp = (float)svhp[e];
+          dn[e] = dh[e] * (1.0f - z) * (1.0f - n * n);
+          dz[e] = dh[e] * (hp - n) * z * (1.0f - z);
+          dr[e] = dn[e] * hn * r * (1.0f - r);
+          dnr[e] = dn[e] * r;
+          dhz[e] = dh[e] * z;
+        }
+        *reinterpret_cast<f32x4*>(carry + (long)b * H + u0) = f32x4{dhz[0], dhz[1], dhz[2], dhz[3]};
+        const unsigned og = (unsigned)(((long)b * 3 * H + u0) * 2);
+        const bf16x4 vr = to_bf16x4(dr), vz = to_bf16x4(dz);
+        store_sc1_b64(r_dGH, og, vr);
+        store_sc1_b64(r_dGH, og + H * 2, vz);
+        store_sc1_b64(r_dGH, og + 2 * H * 2, to_bf16x4(dnr));
+        store_sc1_b64(r_dGI, og, vr);
+        store_sc1_b64(r_dGI, og + H * 2, vz);
+        store_sc1_b64(r_dGI, og + 2 * H * 2, to_bf16x4(dn));
+      }
+    }
+    // ---- publish step t of this unit slice (also: every wave is done with the ring before the next step refills it)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && t >= 0) __hip_atomic_fetch_add(cnt_own, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void dec_bwd_persist_kernel(DecBwdPersist a, Sched sd) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int g = blockIdx.x % a.NG, k = blockIdx.x / a.NG;   // blockIdx % 8 labels the XCD: a group's workgroups share one
+  constexpr int NCU = H / 64;
+  const int l = a.L - 1 - k / NCU, c = k % NCU;             // top layer first: it is the head of the dependency chain
+  if (l == a.L - 1) dec_bwd_body<H, true>(a, sd, g, l, c, smem);
+  else dec_bwd_body<H, false>(a, sd, g, l, c, smem);
+}
+
+// dh0 = sum over layers of the per-layer h0 gradients (every layer starts from the same decoder_lat(z))
+__global__ void dh0_sum_kernel(DecBwdPersist a, long n, float* out32, bf16_t* out_op) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(a.dh0[0] + i);
+  for (int l = 1; l < a.L; ++l) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(a.dh0[l] + i);
+    s += v;
+  }
+  *reinterpret_cast<f32x4*>(out32 + i) = s;
+  const float v[4] = {s[0], s[1], s[2], s[3]};
+  *reinterpret_cast<bf16x4*>(out_op + i) = to_bf16x4(v);
+}
+
+}  // namespace
+
+int launch_dec_bwd_persist(DecBwdPersist& a, const Sched& sd, int H, float* dh0_32, bf16_t* dh0_op, hipStream_t stream) {
+  PG_REQUIRE(dec_persist_supported(H, a.L, a.B), "dec_bwd_persist: shape H=%d L=%d not covered", H, a.L);
+  PG_REQUIRE(a.sync && a.dout && dh0_32 && dh0_op, "dec_bwd_persist: NULL buffer");
+  for (int l = 0; l < a.L; ++l)
+    PG_REQUIRE(a.WhhT[l] && (l == 0 || a.WihT[l]) && a.dGI[l] && a.dGH[l] && a.carry[l] && a.dh0[l] && a.sv[l][0],
+               "dec_bwd_persist: NULL buffer (layer %d)", l);
+  using GL = BwdGeo<512, false>;
+  using GT = BwdGeo<512, true>;
+  constexpr int SMEM = GL::SMEM > GT::SMEM ? GL::SMEM : GT::SMEM;
+  a.NG = 8;
+  PG_TRY(persist_fail_words(&a.fail));
+  PG_CHECK_HIP(hipMemsetAsync(a.sync, 0, PG_PERSIST_SYNC_WORDS * sizeof(unsigned), stream));
+  static bool attr_done = false;
+  if (!attr_done) {
+    PG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_persist_kernel<512>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_done = true;
+  }
+  const int grid = a.NG * a.L * GL::NCU;   // co-residency: one workgroup per CU (checked against the CU count by the forward launcher's rule)
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    PG_CHECK_HIP(hipGetDevice(&dev));
+    PG_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  PG_REQUIRE(grid <= n_cu, "dec_bwd_persist: %d workgroups cannot be co-resident on %d CUs", grid, n_cu);
+  hipLaunchKernelGGL((dec_bwd_persist_kernel<512>), dim3(grid), dim3(256), (size_t)SMEM, stream, a, sd);
+  PG_CHECK_LAUNCH();
+  PG_TRY(persist_fail_mirror(stream));
+  const long n = (long)a.B * H;
+  hipLaunchKernelGGL(dh0_sum_kernel, dim3(cdiv(n, 4 * 256)), dim3(256), 0, stream, a, n, dh0_32, dh0_op);
+  PG_CHECK_LAUNCH();
+  return PG_OK;
+}

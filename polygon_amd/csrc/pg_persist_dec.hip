@@ -312,18 +312,28 @@ bool dec_persist_supported(int H, int L, int B) { return H == 512 && L >= 1 && L
 
 int persist_poll_failure() { return g_fail_host ? *reinterpret_cast<volatile int*>(g_fail_host) : 0; }
 
-int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t stream) {
-  PG_REQUIRE(dec_persist_supported(H, a.L, a.B), "dec_fwd_persist: shape H=%d L=%d not covered", H, a.L);
-  PG_REQUIRE(a.sync && a.table && a.tok && a.zproj && a.h0_op && a.h0_32, "dec_fwd_persist: NULL buffer");
-  using G = DecGeo<512>;
-  a.NG = 8;   // one group per XCD
+int persist_fail_words(unsigned** dev) {
   if (!g_fail_host) {
     PG_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&g_fail_host), 64, hipHostMallocDefault));
     *g_fail_host = 0;
     PG_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&g_fail_dev), 64));
     PG_CHECK_HIP(hipMemset(g_fail_dev, 0, 64));
   }
-  a.fail = g_fail_dev;
+  *dev = g_fail_dev;
+  return PG_OK;
+}
+
+int persist_fail_mirror(hipStream_t stream) {
+  PG_CHECK_HIP(hipMemcpyAsync(g_fail_host, g_fail_dev, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+  return PG_OK;
+}
+
+int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t stream) {
+  PG_REQUIRE(dec_persist_supported(H, a.L, a.B), "dec_fwd_persist: shape H=%d L=%d not covered", H, a.L);
+  PG_REQUIRE(a.sync && a.table && a.tok && a.zproj && a.h0_op && a.h0_32, "dec_fwd_persist: NULL buffer");
+  using G = DecGeo<512>;
+  a.NG = 8;   // one group per XCD
+  PG_TRY(persist_fail_words(&a.fail));
   a.stamps = g_stamps;
   PG_CHECK_HIP(hipMemsetAsync(a.sync, 0, PG_PERSIST_SYNC_WORDS * sizeof(unsigned), stream));
   static bool attr_done = false;
@@ -345,7 +355,7 @@ int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t
   PG_REQUIRE(grid <= n_cu, "dec_fwd_persist: %d workgroups cannot be co-resident on %d CUs", grid, n_cu);
   hipLaunchKernelGGL((dec_fwd_persist_kernel<512>), dim3(grid), dim3(256), (size_t)G::SMEM, stream, a, sd);
   PG_CHECK_LAUNCH();
-  PG_CHECK_HIP(hipMemcpyAsync(g_fail_host, g_fail_dev, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+  PG_TRY(persist_fail_mirror(stream));
   return PG_OK;
 }
 

@@ -169,26 +169,32 @@ static inline long sum_len(const int32_t* l, int B) {
   return s;
 }
 
-// the row-resident persistent recurrence (pg_persist.h) unless the size is not covered; PG_NO_PERSIST=1 forces the per-step
-// kernels (A/B timing and a second implementation for the parity tests)
-static bool use_persistent(int H) {
-  static const bool off = getenv("PG_NO_PERSIST") && (atoi(getenv("PG_NO_PERSIST")) & 1) != 0;   // bit 0 encoder, bit 1 decoder
-  return !off && enc_persist_supported(H);
+// The persistent recurrence kernels (pg_persist.h) run unless the size is not covered.  PG_NO_PERSIST=<mask> (environment,
+// read once) or pg_persist_disable(mask) force the per-step kernels: bit 0 encoder, bit 1 decoder forward, bit 2 decoder
+// BPTT (A/B timing, and a second implementation for the parity tests).
+static int g_persist_off = -1;
+static int persist_off_mask() {
+  if (g_persist_off < 0) g_persist_off = getenv("PG_NO_PERSIST") ? atoi(getenv("PG_NO_PERSIST")) & 7 : 0;
+  return g_persist_off;
 }
+extern "C" int pg_persist_disable(int mask) {
+  const int old = persist_off_mask();
+  if (mask >= 0) g_persist_off = mask & 7;
+  return old;
+}
+static bool use_persistent(int H) { return !(persist_off_mask() & 1) && enc_persist_supported(H); }
 
 // a persistent kernel of an earlier call gave up waiting for a peer workgroup (it was not co-resident): everything computed
 // since is suspect, so every later call fails loudly instead of returning numbers
 static int check_persist() {
   PG_REQUIRE(persist_poll_failure() == 0,
              "a persistent recurrence kernel timed out waiting for its peer workgroups (GPU shared or partially available?); "
-             "set PG_NO_PERSIST=3 to use the per-step kernels");
+             "set PG_NO_PERSIST=7 to use the per-step kernels");
   return PG_OK;
 }
 
-static bool use_persistent_dec(int H, int L, int B) {
-  static const bool off = getenv("PG_NO_PERSIST") && (atoi(getenv("PG_NO_PERSIST")) & 2) != 0;
-  return !off && dec_persist_supported(H, L, B);
-}
+static bool use_persistent_dec(int H, int L, int B) { return !(persist_off_mask() & 2) && dec_persist_supported(H, L, B); }
+static bool use_persistent_dec_bwd(int H, int L, int B) { return !(persist_off_mask() & 4) && dec_persist_supported(H, L, B); }
 
 template <typename T> static int convert_to(const float* in, T* out, long n, hipStream_t st) {
   hipLaunchKernelGGL(convert_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, st, in, out, n);
@@ -470,9 +476,35 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   const bool drop = p_drop > 0.0f;
   // BPTT as a wavefront: cell (l, t) needs (l, t+1) and (l+1, t); the gradient coming down from layer l+1 is
   // computed inside the cell (dGI_{l+1,t} . W_ih_{l+1}, through layer l's dropout mask), so no per-layer dX GEMM.
-  const int pslot = prof_begin(1, st);
+  bool persist = false;
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    if (use_persistent_dec_bwd(Hd, L, B)) {   // ONE launch: W_hh^T / W_ih_up^T rows stationary per workgroup, layers pipelined top-down
+      DecBwdPersist pa;
+      pa.L = L; pa.B = B;
+      for (int l = 0; l < L; ++l) {
+        pa.WhhT[l] = at<T>(shadow, so.whhT[l]);
+        if (l > 0) pa.WihT[l] = at<T>(shadow, so.wihT[l]);
+        for (int i = 0; i < 5; ++i) pa.sv[l][i] = at<T>(ws, w.d_sv[l][i]);
+        pa.dGI[l] = at<T>(ws, w.b_dGI_l[l]); pa.dGH[l] = at<T>(ws, w.b_dGH_l[l]);
+        pa.carry[l] = at<float>(ws, w.b_dhz_l[l][0]); pa.dh0[l] = at<float>(ws, w.b_dhz_l[l][1]);
+      }
+      pa.dout = dout;
+      pa.p_drop = p_drop; pa.seed = seed; pa.b_mul = b_mul; pa.b_add = b_add;
+      pa.sync = at<unsigned>(ws, w.sync);
+      const int ps = prof_begin(1, st);
+      PG_TRY(launch_dec_bwd_persist(pa, sd, Hd, dh0, at<T>(ws, w.b_dh0_op), st));
+      double pf = 0.0;   // algorithmic flop: dh = dGH_{t+1}.W_hh (+ dGI_{l+1,t}.W_ih_{l+1} below the top layer)
+      for (int t = -1; t < sd.T; ++t) {
+        const double rin = t + 1 < sd.T ? sched_B(sd, t + 1) : 0, rout = t >= 0 ? sched_B(sd, t) : 0;
+        pf += 2.0 * 3.0 * Hd * Hd * (L * rin + (L - 1) * rout);
+      }
+      prof_end(1, ps, st, 1, pf);
+      persist = true;
+    }
+  }
+  const int pslot = persist ? -1 : prof_begin(1, st);
   double pflop = 0.0;
-  for (int dgi = 0; dgi < sd.T + L; ++dgi) {
+  for (int dgi = 0; dgi < sd.T + L && !persist; ++dgi) {
     GruBwdDiag<T> dg;
     for (int l = L - 1; l >= 0; --l) {
       const int t = sd.T - 1 - (dgi - (L - 1 - l));
@@ -548,7 +580,7 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   }
   // decoder_lat: h0 = W z + b feeds every layer
   T* dh0_op = at<T>(ws, w.b_dh0_op);
-  PG_TRY(convert_to<T>(dh0, dh0_op, (long)B * Hd, st));
+  if (!persist) PG_TRY(convert_to<T>(dh0, dh0_op, (long)B * Hd, st));
   PG_TRY(launch_gemm_tn<T>(dh0_op, Hd, at<T>(ws, w.d_zop), Dz, Hd, Dz, B, grads + po.lat_w, Dz, 1.0f, nullptr, st, grads + po.lat_b));
   {
     GemmEpi<T> e;

@@ -43,7 +43,7 @@ for batch in loader:
     tot += len(batch)
 assert tot == 100
 dist.barrier(); dist.destroy_process_group()
-print("rank", rank, "ok")
+sys.stdout.write("rank %%d ok\n" %% rank); sys.stdout.flush()   # one write: the two ranks share the pipe
 '''
 
 

@@ -1,0 +1,55 @@
+"""The persistent recurrence kernels (pg_persist.h) against the per-step kernels they replace: same batch, same
+dropout seed, same eps -> the two implementations must agree to bf16 rounding on losses and on every gradient.
+Sizes cover more than one 16-row tile per group, groups that run out of sequences early, and a batch smaller than the
+number of groups."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vae_oracle as O
+from polygon_amd import _lib
+from tests.helpers import REAL, build_model, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(model, opt, batch, eps, p_drop, mask):
+    L = _lib.lib()
+    old = L.pg_persist_disable(mask)
+    try:
+        kl, rec = model._engine.train_step(batch, 0.5, opt.flat_grad, eps=eps, p_drop=p_drop, seed=4242)
+        torch.cuda.synchronize()
+        return kl.item(), rec.item(), opt.flat_grad.clone()
+    finally:
+        L.pg_persist_disable(old)
+
+
+@pytest.mark.parametrize("n,p_drop", [(300, 0.2), (5, 0.0), (77, 0.0), (1024, 0.2)])
+def test_persistent_matches_per_step(n, p_drop):
+    from polygon_amd.vae.vae_trainer import FusedClipAdam
+    model, _ = build_model(REAL, 21, "bf16", d_dropout=p_drop)
+    model.train()
+    strings = O.synthetic_smiles(n, seed=n)
+    if n > 8:
+        strings = list(strings[:-3]) + ["", "C", "C" * 98]
+    batch = model.get_collate_fn()(list(strings))
+    eps = torch.from_numpy(np.random.default_rng(n).standard_normal((n, REAL["Dz"])).astype(np.float32)).cuda()
+    opt = FusedClipAdam(model, lr=0.0)
+    ref = _run(model, opt, batch, eps, p_drop, 7)          # every recurrence on the per-step kernels
+    for mask in (3, 0):                                    # 3: only the decoder BPTT persistent; 0: everything persistent
+        got = _run(model, opt, batch, eps, p_drop, mask)
+        assert abs(got[0] - ref[0]) <= 2e-3 * abs(ref[0]), (mask, got[0], ref[0])
+        assert abs(got[1] - ref[1]) <= 2e-3 * abs(ref[1]), (mask, got[1], ref[1])
+        assert torch.isfinite(got[2]).all()
+        # per parameter tensor, relative to that tensor's largest gradient entry
+        off = 0
+        for i, p in enumerate(model._engine.params()):   # flat order = optimiser order
+            k = p.numel()
+            a, b = got[2][off:off + k], ref[2][off:off + k]
+            assert rel_err(a, b) <= 2e-2, (mask, i, tuple(p.shape), rel_err(a, b))
+            off += k
+    # determinism of the persistent path: run to run identical apart from the fp32 atomics of the weight-gradient GEMMs
+    a = _run(model, opt, batch, eps, p_drop, 0)
+    b = _run(model, opt, batch, eps, p_drop, 0)
+    assert abs(a[0] - b[0]) <= 1e-6 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-6 * abs(a[1])   # loss sums are fp32 atomics
+    assert rel_err(a[2], b[2]) <= 1e-4
