@@ -45,7 +45,7 @@ typedef struct pg_dims {
 /* data-parallel context of one call: rank r of G holds rows r, r+G, ... of the
  * globally sorted batch.  kl_inv_batch = 1/B_global; ce_count = global number of non-pad targets
  * (<= 0: use the locally counted value); b_mul/b_add map a local row to its global row
- * (b*b_mul + b_add) so the dropout Philox stream is independent of G. */
+ * (b*b_mul + b_add) so the dropout mask (a counter hash of seed, layer, t, global row, column) is independent of G. */
 typedef struct pg_dp {
   float kl_inv_batch;
   float ce_count;

@@ -45,11 +45,13 @@ template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of an IEEE division: the gate epilogues run on ONE wave per SIMD in the persistent kernels,
+// where every VALU instruction is exposed
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) {
-  // tanh(x) = 1 - 2/(exp(2x)+1); exact limits at +-inf, abs error ~1e-7
+  // tanh(x) = 1 - 2/(exp(2x)+1); exact limits at +-inf, abs error ~2e-7
   float e = __expf(2.0f * x);
-  return 1.0f - 2.0f / (e + 1.0f);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 
 // ---- Philox4x32-10 (counter-based RNG; same stream whatever the launch geometry) ------------
@@ -75,16 +77,28 @@ __host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t 
 // uniform in [0,1) with 24 bits
 __host__ __device__ __forceinline__ float pg_u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 
-// dropout keep/scale factors: ONE Philox call covers the 4 consecutive columns 4*col4 .. 4*col4+3 of
-// (layer, t, global batch row); p = drop probability.  Every kernel (forward mask, BPTT mask) goes through these two.
+// dropout keep/scale factors of the 4 consecutive columns 4*col4 .. 4*col4+3 of (layer, t, global batch row); p = drop
+// probability.  Every kernel (forward mask, BPTT mask) goes through these two, so the mask is a pure function of its
+// coordinates whatever the launch geometry.  A counter hash (three rounds of the lowbias32 integer mixer: 6 integer
+// multiplies for 4 masks) rather than Philox-10 (40 quarter-rate multiplies): the mask is recomputed in the gate epilogue
+// of every cell, forward and backward.  Each mask compares a 16-bit uniform with round(p * 65536).
+__host__ __device__ __forceinline__ uint32_t pg_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du;
+  x ^= x >> 15; x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
 __device__ __forceinline__ void dropout_scale4(uint64_t seed, int layer, int t, int bglob, int col4, float p, float inv_keep,
                                                float (&m)[4]) {
-  Philox4 r = philox4x32_10((uint32_t)col4, (uint32_t)bglob, (uint32_t)t, (uint32_t)layer, (uint32_t)seed,
-                            (uint32_t)(seed >> 32));
-  m[0] = pg_u01(r.x) >= p ? inv_keep : 0.0f;
-  m[1] = pg_u01(r.y) >= p ? inv_keep : 0.0f;
-  m[2] = pg_u01(r.z) >= p ? inv_keep : 0.0f;
-  m[3] = pg_u01(r.w) >= p ? inv_keep : 0.0f;
+  const uint32_t rowkey = pg_mix32((uint32_t)seed ^ ((uint32_t)bglob * 0x9E3779B1u) ^ ((uint32_t)t * 0x85EBCA77u) ^
+                                   ((uint32_t)layer * 0xC2B2AE3Du) ^ (uint32_t)(seed >> 32) * 0x27D4EB2Fu);
+  const uint32_t w0 = pg_mix32(rowkey + (uint32_t)col4 * 0x9E3779B9u);
+  const uint32_t w1 = pg_mix32(w0 ^ 0x68E31DA4u);
+  const uint32_t thr = (uint32_t)(p * 65536.0f + 0.5f);
+  m[0] = (w0 & 0xFFFFu) >= thr ? inv_keep : 0.0f;
+  m[1] = (w0 >> 16) >= thr ? inv_keep : 0.0f;
+  m[2] = (w1 & 0xFFFFu) >= thr ? inv_keep : 0.0f;
+  m[3] = (w1 >> 16) >= thr ? inv_keep : 0.0f;
 }
 __device__ __forceinline__ float dropout_scale(uint64_t seed, int layer, int t, int bglob, int col, float p, float inv_keep) {
   float m[4];

@@ -68,6 +68,7 @@ struct DecFwdPersist {
   unsigned* sync = nullptr;                   // PG_PERSIST_SYNC_WORDS words, zeroed by the launcher
   unsigned* fail = nullptr;                   // set by the launcher: process-wide sticky give-up word
   unsigned long long* stamps = nullptr;       // development aid: wall-clock stamps of one workgroup (pg_persist_stamps)
+  int dbg = 0;                                // development aid (PG_PERSIST_DBG): 1 no DMA, 2 no MFMA, 4 no epilogue stores, 8 no epilogue loads
 };
 constexpr int PG_PERSIST_SYNC_WORDS = 1040;   // counters [8 groups][PG_MAX_LAYERS] at a 16-word stride, then the give-up word
 
@@ -89,6 +90,8 @@ struct DecBwdPersist {
   int b_mul = 1, b_add = 0;
   unsigned* sync = nullptr;                   // PG_PERSIST_SYNC_WORDS words, zeroed by the launcher
   unsigned* fail = nullptr;                   // set by the launcher
+  unsigned long long* stamps = nullptr;       // development aid (pg_persist_stamps)
+  int dbg = 0;                                // development aid (PG_PERSIST_DBG): 1 no DMA, 2 no MFMA, 4 no epilogue I/O
 };
 
 bool dec_persist_supported(int H, int L, int B);
@@ -99,6 +102,8 @@ int launch_dec_bwd_persist(DecBwdPersist& a, const Sched& sd, int H, float* dh0_
 // stream-ordered copy to its pinned host mirror that persist_poll_failure() reads
 int persist_fail_words(unsigned** dev);
 int persist_fail_mirror(hipStream_t stream);
+bool persist_dma_plain();
+unsigned long long* persist_stamps_for(int which);   // development aid: stamp buffer if tracing kernel `which`, else null
 // nonzero once a persistent kernel of this process gave up waiting on another workgroup (checked by every entry point)
 int persist_poll_failure();
 

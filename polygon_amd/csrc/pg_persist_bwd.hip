@@ -39,8 +39,9 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float (&v)[4]) {
   o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
   return o;
 }
-__device__ __forceinline__ void store_sc1_b64(__amdgpu_buffer_rsrc_t r, unsigned byte_off, const bf16x4& v) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)byte_off, 0, AUX_SC1);
+template <int AUXS>
+__device__ __forceinline__ void store_pub_b64(__amdgpu_buffer_rsrc_t r, unsigned byte_off, const bf16x4& v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)byte_off, 0, AUXS);
 }
 
 __device__ __forceinline__ bool wait_ge(unsigned* p, unsigned target, unsigned* err, unsigned* sticky) {
@@ -71,6 +72,13 @@ __device__ __forceinline__ void wait_parts(int younger) {
   }
 }
 
+// development aid: workgroup (g 0, traced layer, slice 0) records wall-clock stamps (100 MHz) of its steps 8..15
+#define PG_STAMP(slot)                                                                                   \
+  do {                                                                                                   \
+    if (a.stamps && tid == 0 && g == 0 && c == 0 && l == (int)a.stamps[0] && s >= (int)a.stamps[1] && s < (int)a.stamps[1] + 8) \
+      a.stamps[8 + (s - (int)a.stamps[1]) * 8 + (slot)] = wall_clock64();                                               \
+  } while (0)
+
 template <int H, bool TOP> struct BwdGeo {
   static constexpr int KS = 3 * H / 32;          // MFMA K steps over the 3H gate columns
   static constexpr int KSP = 16;                 // K steps per part
@@ -83,7 +91,7 @@ template <int H, bool TOP> struct BwdGeo {
   static constexpr int SMEM = WN_BYTES + NSLOT * PART_BYTES + 16;
 };
 
-template <int H, bool TOP>
+template <int H, bool TOP, int AUXL>
 __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched& sd, int g, int l, int c, char* smem) {
   using G = BwdGeo<H, TOP>;
   constexpr int NCU = G::NCU, ROWW = G::ROWW, NSLOT = G::NSLOT, D = G::D;
@@ -137,16 +145,19 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
     const int t = Tg - 1 - s;                      // t = -1: the gradient of h0
     const bool has_own = s > 0;                    // step t+1 of this group exists
     const bool has_up = !TOP && t >= 0;
+    PG_STAMP(0);
     // ---- wait for dGH_{l,t+1} (own layer) and dGI_{l+1,t} (layer above)
     if (tid == 0) {
       bool ok = wait_ge(cnt_own, (unsigned)(NCU * s), err, a.fail);
       if (has_up && ok) ok = wait_ge(cnt_up, (unsigned)(NCU * (s + 1)), err, a.fail);
+      PG_STAMP(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       *sFlag = ok ? 1u : 0u;
     }
     __syncthreads();
     if (*sFlag == 0u) return;   // block-uniform: somebody gave up
+    PG_STAMP(2);
     const int tt = t >= 0 ? t : 0;
     const int o = sd.off[tt], Bt = sd.off[tt + 1] - o;             // rows of this step (t = -1: those of step 0)
     const int o1 = t >= 0 ? sd.off[t + 1] : 0;                      // rows that carry a recurrent gradient: step t+1
@@ -163,7 +174,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
     // flattened part sequence of the step: tile-major, own parts before upper parts
     int qi = 0, ji = 0, pi = 0, si = 0;            // next part to issue: index, tile, part in tile, slot
     auto issue = [&]() __attribute__((always_inline)) {
-      if (qi < nparts) {                           // block-uniform
+      if (qi < nparts && !(a.dbg & 1)) {           // block-uniform
         const bool own = has_own && pi < 3;
         const int sub = own ? pi : pi - (has_own ? 3 : 0);
         const bf16_t* base = (own ? own_base : up_base) + sub * 512;
@@ -175,7 +186,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
           const int bs = b < lim ? b : g;          // finished sequences re-read a valid row; their columns are masked
           const bf16_t* src = base + (long)bs * 3 * H + ((lane ^ row) * 8);
           char* dst = sR + si * PART_BYTES + row * 1024;
-          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, AUX_SC1);
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, AUXL);
         }
       }
       ++qi;
@@ -186,11 +197,12 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
 #pragma unroll 1
       for (int i = 0; i <= D; ++i) issue();
     }
+    PG_STAMP(3);
     int qc = 0, sc = 0;                            // part being consumed, its slot
     // one part: wait for its DMAs, publish them, refill the slot freed by the previous part, 16 K-steps
     auto part_begin = [&]() __attribute__((always_inline)) -> const char* {
       const int younger = nparts - 1 - qc;
-      wait_parts(younger < D ? younger : D);
+      if (!(a.dbg & 1)) wait_parts(younger < D ? younger : D);
       // a bare s_barrier: __syncthreads() carries a workgroup release fence = vmcnt(0), which would drain the very DMAs
       // this pipeline keeps in flight.  Nothing but the DMA'd slot is communicated here (the wave's own LDS reads of the
       // previous part were consumed by its MFMAs), so the counted wait above is the only ordering needed.
@@ -210,8 +222,8 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
       // epilogue inputs of this lane's sequence, fetched under the tile's MFMAs
       f32x4 cr = f32x4{0.f, 0.f, 0.f, 0.f}, dtop = f32x4{0.f, 0.f, 0.f, 0.f};
       bf16x4 svr, svz, svn, svhn, svhp;
-      if (has_own) cr = *reinterpret_cast<const f32x4*>(carry + (long)bs * H + u0);
-      if (t >= 0) {
+      if (has_own && !(a.dbg & 4)) cr = *reinterpret_cast<const f32x4*>(carry + (long)bs * H + u0);
+      if (t >= 0 && !(a.dbg & 4)) {
         const long sidx = (long)(o + bs) * H + u0;
         if constexpr (TOP) dtop = *reinterpret_cast<const f32x4*>(a.dout + sidx);
         svr = *reinterpret_cast<const bf16x4*>(a.sv[l][0] + sidx);
@@ -227,12 +239,25 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
           const char* A = part_begin();
-          bf16x8 xc = *reinterpret_cast<const bf16x8*>(A + ((0 ^ hi) << 6)), xn = xc;
+          if (a.dbg & 2) continue;
+          // the part's 16 activation fragments are read in groups of 4, two groups (8 reads, <= 0.5 us of MFMAs) ahead of
+          // the MFMAs that consume them; the scheduling barriers keep hipcc from sinking the reads back to their uses
+          bf16x8 f[4][4];
 #pragma unroll
-          for (int ks = 0; ks < 16; ++ks) {
-            if (ks + 1 < 16) xn = *reinterpret_cast<const bf16x8*>(A + (((ks + 1) ^ hi) << 6));
-            ah[ks & 1] = mma16(wh[p * 16 + ks], xc, ah[ks & 1]);
-            xc = xn;
+          for (int gk = 0; gk < 2; ++gk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[gk][i] = *reinterpret_cast<const bf16x8*>(A + (((gk * 4 + i) ^ hi) << 6));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int gk = 0; gk < 4; ++gk) {
+            if (gk + 2 < 4) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) f[gk + 2][i] = *reinterpret_cast<const bf16x8*>(A + ((((gk + 2) * 4 + i) ^ hi) << 6));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ah[i & 1] = mma16(wh[p * 16 + gk * 4 + i], f[gk][i], ah[i & 1]);
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
@@ -241,31 +266,67 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
             const char* A = part_begin();
-            bf16x8 xc = *reinterpret_cast<const bf16x8*>(A + ((0 ^ hi) << 6)), xn = xc;
+            if (a.dbg & 2) continue;
+            // the part's 16 activation fragments are read in groups of 4, two groups (8 reads, <= 0.5 us of MFMAs) ahead of
+            // the MFMAs that consume them; the scheduling barriers keep hipcc from sinking the reads back to their uses
+            bf16x8 f[4][4];
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-              if (ks + 1 < 16) xn = *reinterpret_cast<const bf16x8*>(A + (((ks + 1) ^ hi) << 6));
-              au[ks & 1] = mma16(wu[p * 16 + ks], xc, au[ks & 1]);
-              xc = xn;
+            for (int gk = 0; gk < 2; ++gk)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) f[gk][i] = *reinterpret_cast<const bf16x8*>(A + (((gk * 4 + i) ^ hi) << 6));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int gk = 0; gk < 4; ++gk) {
+              if (gk + 2 < 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) f[gk + 2][i] = *reinterpret_cast<const bf16x8*>(A + ((((gk + 2) * 4 + i) ^ hi) << 6));
+              }
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) au[i & 1] = mma16(wu[p * 16 + gk * 4 + i], f[gk][i], au[i & 1]);
+              __builtin_amdgcn_sched_barrier(0);
             }
           }
           {
             const char* A = part_begin();
             const char* Wn = sWn + (wave * 16 + lr) * ROWW + lq * 16;
-            bf16x8 xc = *reinterpret_cast<const bf16x8*>(A + ((0 ^ hi) << 6)), xn = xc;
-            bf16x8 wc = *reinterpret_cast<const bf16x8*>(Wn), wn = wc;
+            if (!(a.dbg & 2)) {
+            // activation and weight fragments both come from LDS here: groups of 4 K-steps, one group ahead
+            bf16x8 xa[4], wa[4], xb[4], wb[4];
 #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-              if (ks + 1 < 16) {
-                xn = *reinterpret_cast<const bf16x8*>(A + (((ks + 1) ^ hi) << 6));
-                wn = *reinterpret_cast<const bf16x8*>(Wn + (ks + 1) * 64);
+            for (int i = 0; i < 4; ++i) {
+              xa[i] = *reinterpret_cast<const bf16x8*>(A + ((i ^ hi) << 6));
+              wa[i] = *reinterpret_cast<const bf16x8*>(Wn + i * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int gk = 0; gk < 4; ++gk) {
+              if (gk + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const int ks = (gk + 1) * 4 + i;
+                  if (gk & 1) {
+                    xa[i] = *reinterpret_cast<const bf16x8*>(A + ((ks ^ hi) << 6));
+                    wa[i] = *reinterpret_cast<const bf16x8*>(Wn + ks * 64);
+                  } else {
+                    xb[i] = *reinterpret_cast<const bf16x8*>(A + ((ks ^ hi) << 6));
+                    wb[i] = *reinterpret_cast<const bf16x8*>(Wn + ks * 64);
+                  }
+                }
               }
-              au[ks & 1] = mma16(wc, xc, au[ks & 1]);
-              xc = xn; wc = wn;
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                if (gk & 1) au[i & 1] = mma16(wb[i], xb[i], au[i & 1]);
+                else au[i & 1] = mma16(wa[i], xa[i], au[i & 1]);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
             }
           }
         }
       }
+      if (j == 0) PG_STAMP(4);
       // ---- epilogue on 4 units of sequence b
       float dh[4];
       float m[4] = {1.0f, 1.0f, 1.0f, 1.0f};
@@ -281,7 +342,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
         if (live) *reinterpret_cast<f32x4*>(a.dh0[l] + (long)b * H + u0) = f32x4{dh[0], dh[1], dh[2], dh[3]};
         continue;
       }
-      if (live) {
+      if (live && !((a.dbg & 4) && dh[0] != 12345.678f)) {
         float dr[4], dz[4], dn[4], dnr[4], dhz[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -295,29 +356,38 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
         *reinterpret_cast<f32x4*>(carry + (long)b * H + u0) = f32x4{dhz[0], dhz[1], dhz[2], dhz[3]};
         const unsigned og = (unsigned)(((long)b * 3 * H + u0) * 2);
         const bf16x4 vr = to_bf16x4(dr), vz = to_bf16x4(dz);
-        store_sc1_b64(r_dGH, og, vr);
-        store_sc1_b64(r_dGH, og + H * 2, vz);
-        store_sc1_b64(r_dGH, og + 2 * H * 2, to_bf16x4(dnr));
-        store_sc1_b64(r_dGI, og, vr);
-        store_sc1_b64(r_dGI, og + H * 2, vz);
-        store_sc1_b64(r_dGI, og + 2 * H * 2, to_bf16x4(dn));
+        store_pub_b64<AUXL>(r_dGH, og, vr);
+        store_pub_b64<AUXL>(r_dGH, og + H * 2, vz);
+        store_pub_b64<AUXL>(r_dGH, og + 2 * H * 2, to_bf16x4(dnr));
+        store_pub_b64<AUXL>(r_dGI, og, vr);
+        store_pub_b64<AUXL>(r_dGI, og + H * 2, vz);
+        store_pub_b64<AUXL>(r_dGI, og + 2 * H * 2, to_bf16x4(dn));
       }
     }
+    PG_STAMP(5);
     // ---- publish step t of this unit slice (also: every wave is done with the ring before the next step refills it)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0 && t >= 0) __hip_atomic_fetch_add(cnt_own, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    PG_STAMP(6);
+    if (tid == 0 && t >= 0) {
+      if constexpr (AUXL == 0) {   // plain payload stores: lane-0 agent release (L2 write-back) before the arrival
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __hip_atomic_fetch_add(cnt_own, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    PG_STAMP(7);
   }
 }
 
-template <int H>
+template <int H, int AUXL>
 __global__ __launch_bounds__(256) void dec_bwd_persist_kernel(DecBwdPersist a, Sched sd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int g = blockIdx.x % a.NG, k = blockIdx.x / a.NG;   // blockIdx % 8 labels the XCD: a group's workgroups share one
   constexpr int NCU = H / 64;
   const int l = a.L - 1 - k / NCU, c = k % NCU;             // top layer first: it is the head of the dependency chain
-  if (l == a.L - 1) dec_bwd_body<H, true>(a, sd, g, l, c, smem);
-  else dec_bwd_body<H, false>(a, sd, g, l, c, smem);
+  if (l == a.L - 1) dec_bwd_body<H, true, AUXL>(a, sd, g, l, c, smem);
+  else dec_bwd_body<H, false, AUXL>(a, sd, g, l, c, smem);
 }
 
 // dh0 = sum over layers of the per-layer h0 gradients (every layer starts from the same decoder_lat(z))
@@ -347,10 +417,14 @@ int launch_dec_bwd_persist(DecBwdPersist& a, const Sched& sd, int H, float* dh0_
   constexpr int SMEM = GL::SMEM > GT::SMEM ? GL::SMEM : GT::SMEM;
   a.NG = 8;
   PG_TRY(persist_fail_words(&a.fail));
+  a.stamps = persist_stamps_for(1);
+  a.dbg = getenv("PG_PERSIST_DBG") ? atoi(getenv("PG_PERSIST_DBG")) : 0;
   PG_CHECK_HIP(hipMemsetAsync(a.sync, 0, PG_PERSIST_SYNC_WORDS * sizeof(unsigned), stream));
   static bool attr_done = false;
   if (!attr_done) {
-    PG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_persist_kernel<512>),
+    PG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, AUX_SC1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    PG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, 0>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_done = true;
   }
@@ -362,7 +436,10 @@ int launch_dec_bwd_persist(DecBwdPersist& a, const Sched& sd, int H, float* dh0_
     PG_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
   }
   PG_REQUIRE(grid <= n_cu, "dec_bwd_persist: %d workgroups cannot be co-resident on %d CUs", grid, n_cu);
-  hipLaunchKernelGGL((dec_bwd_persist_kernel<512>), dim3(grid), dim3(256), (size_t)SMEM, stream, a, sd);
+  if (persist_dma_plain())
+    hipLaunchKernelGGL((dec_bwd_persist_kernel<512, 0>), dim3(grid), dim3(256), (size_t)SMEM, stream, a, sd);
+  else
+    hipLaunchKernelGGL((dec_bwd_persist_kernel<512, AUX_SC1>), dim3(grid), dim3(256), (size_t)SMEM, stream, a, sd);
   PG_CHECK_LAUNCH();
   PG_TRY(persist_fail_mirror(stream));
   const long n = (long)a.B * H;

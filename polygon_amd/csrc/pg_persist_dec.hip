@@ -38,8 +38,9 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float (&v)[4]) {
   return o;
 }
 // 8-byte write-through store (published data)
-__device__ __forceinline__ void store_sc1_b64(__amdgpu_buffer_rsrc_t r, unsigned byte_off, const bf16x4& v) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)byte_off, 0, AUX_SC1);
+template <int AUXS>
+__device__ __forceinline__ void store_pub_b64(__amdgpu_buffer_rsrc_t r, unsigned byte_off, const bf16x4& v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)byte_off, 0, AUXS);
 }
 __device__ __forceinline__ uint4 load_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
   u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, AUX_SC1);
@@ -63,8 +64,8 @@ __device__ __forceinline__ bool wait_ge(unsigned* p, unsigned target, unsigned* 
 // development aid: workgroup (g 0, layer STAMP_L, slice 0) records wall-clock stamps (100 MHz) of steps 8..15, 8 slots each
 #define PG_STAMP(slot)                                                                                   \
   do {                                                                                                   \
-    if (a.stamps && tid == 0 && g == 0 && c == 0 && l == (int)a.stamps[0] && t >= 8 && t < 16)           \
-      a.stamps[8 + (t - 8) * 8 + (slot)] = wall_clock64();                                               \
+    if (a.stamps && tid == 0 && g == 0 && c == 0 && l == (int)a.stamps[0] && t >= (int)a.stamps[1] && t < (int)a.stamps[1] + 8) \
+      a.stamps[8 + (t - (int)a.stamps[1]) * 8 + (slot)] = wall_clock64();                                               \
   } while (0)
 
 template <int H> struct DecGeo {
@@ -72,18 +73,25 @@ template <int H> struct DecGeo {
   static constexpr int NCU = H / 64;            // workgroups (unit slices) per layer
   static constexpr int ROWW = H * 2 + 16;       // W_in row in LDS (padded)
   static constexpr int WIN_BYTES = 64 * ROWW;
-  static constexpr int TILE_BYTES = 16 * 2 * H * 2;   // activation tile rows [h_{t-1} | x], unpadded (swizzled)
+  static constexpr int ACT_BYTES = 16 * 2 * H * 2;    // activation tile rows [h_{t-1} | x], unpadded (swizzled); layer 0 uses half
+  static constexpr int CARRY_BYTES = 16 * 64 * 4;     // fp32 state slice of the tile's rows (this workgroup's 64 units)
+  static constexpr int GATE_BYTES = 3 * CARRY_BYTES;  // layer 0: gather-table rows / z-projection rows, 3 gates
+  // layers >= 1: W_in rows + 2 x (activations + carry); layer 0 (no W_in, half the activations) fits its two extra
+  // epilogue inputs in the same footprint
+  static constexpr int TILE_BYTES = ACT_BYTES + CARRY_BYTES;
+  static constexpr int TILE0_BYTES = ACT_BYTES / 2 + CARRY_BYTES + 2 * GATE_BYTES;
+  static constexpr int TOK_BYTES = 128 * 4;           // layer 0: the step's tokens of this group (<= 128 sequences)
   static constexpr int SMEM = WIN_BYTES + 2 * TILE_BYTES + 16;   // + the broadcast word of the poll result
+  static_assert(2 * TILE0_BYTES + TOK_BYTES + 16 <= SMEM, "layer-0 layout must fit the common allocation");
 };
 
-template <int H, bool L0>
+template <int H, bool L0, int AUXL>
 __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched& sd, int g, int l, int c, char* smem) {
   using G = DecGeo<H>;
   constexpr int KS = G::KS, NCU = G::NCU, ROWW = G::ROWW;
   static_assert(H == 512, "one LDS-DMA instruction (64 lanes x 16 B) must cover exactly one row half");
   char* sWin = smem;
   char* sA = smem + G::WIN_BYTES;
-  volatile unsigned* sFlag = reinterpret_cast<volatile unsigned*>(smem + G::WIN_BYTES + 2 * G::TILE_BYTES);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
@@ -138,10 +146,31 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
   // LDS (no staging registers).  The destination is lane-linear, so the bank-conflict-free image is made on the SOURCE
   // side: lane p of row r fetches 16-byte chunk p ^ r, i.e. LDS position p of the row holds chunk p ^ (r & 15), and a
   // fragment read of chunk q of row r goes to position q ^ r (16 rows x one 4-chunk group = 16 distinct bank groups).
+  // The epilogue's inputs ride along: the fp32 state slice of the tile (16 rows x 256 B) and, in layer 0, the gather-table
+  // and z-projection rows (3 gates x 256 B per row each) - a quarter of the rows per wave instruction, the same XOR image.
   constexpr int PARTS = L0 ? 1 : 2;                 // row halves per row
   constexpr int RP_WAVE = 16 * PARTS / 4;           // (row, part) pairs per wave per tile
+  constexpr int TILEB = L0 ? G::TILE0_BYTES : G::TILE_BYTES;
+  constexpr int ACTB = G::ACT_BYTES / (L0 ? 2 : 1);
+  char* sT = L0 ? smem : sA;                        // tile buffers (layer 0 has no W_in block in front)
+  int* sTok = reinterpret_cast<int*>(smem + 2 * G::TILE0_BYTES);   // layer 0 only
+  volatile unsigned* sFlagT = reinterpret_cast<volatile unsigned*>(smem + G::SMEM - 16);
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
+  const bool has_drop = hdrop != nullptr, has_sv = a.sv[l][0] != nullptr;     // kernel-uniform
+  const int NS = 2 + (has_drop ? 1 : 0) + (has_sv ? 5 : 0);                     // store instructions per wave and tile
+  const __amdgpu_buffer_rsrc_t r_carry = pg_make_rsrc(carry);
+  // vector memory operations of a wave complete in issue order and loads and stores share ONE counter, so a wait is
+  // written as "all but the youngest n": n = the stores issued after the DMA that must have landed
+  auto wait_all_but = [&](int n) __attribute__((always_inline)) {
+    switch (n) {
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
 
   for (int t = 0; t < Tg; ++t) {
     PG_STAMP(0);
@@ -152,18 +181,24 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
       PG_STAMP(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      *sFlag = ok ? 1u : 0u;
+      *sFlagT = ok ? 1u : 0u;
     }
-    __syncthreads();
-    if (*sFlag == 0u) return;   // block-uniform: somebody gave up, leave (every waiter does the same)
     const int o = sd.off[t], Bt = sd.off[t + 1] - o;
     const int op = t > 0 ? sd.off[t - 1] : 0;
     const int nlive = (Bt - g + NG - 1) / NG;          // sequences g, g+NG, ... below B_t
     const int ntile = (nlive + 15) >> 4;
+    if constexpr (L0) {                                // this step's tokens of the group (nothing else is in flight here)
+      if (tid < 128) sTok[tid] = a.tok[o + (tid < nlive ? g + NG * tid : g)];
+    }
+    __syncthreads();
+    if (*sFlagT == 0u) return;   // block-uniform: somebody gave up, leave (every waiter does the same)
     const bf16_t* hprev_base = t == 0 ? a.h0_op : hseq + (long)op * H;
     const bf16_t* x_base = L0 ? hprev_base : xsrc + (long)o * H;
+    const float* carry_src = (t == 0 ? a.h0_32 : carry) + c * 64;
 
     auto stage = [&](int j, int buf) __attribute__((always_inline)) {
+      if (a.dbg & 1) return;
+      char* tb = sT + buf * TILEB;
 #pragma unroll
       for (int i = 0; i < RP_WAVE; ++i) {
         const int rp = wave * RP_WAVE + i;             // wave-uniform
@@ -171,114 +206,155 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
         const int b = g + NG * (16 * j + row);
         const int bs = b < Bt ? b : g;                 // finished sequences re-read a valid row; their columns are unused
         const bf16_t* src = (part == 0 ? hprev_base : x_base) + (long)bs * H + ((lane ^ (row & 15)) * 8);
-        char* dst = sA + buf * G::TILE_BYTES + row * (PARTS * 1024) + part * 1024;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, AUX_SC1);
+        char* dst = tb + row * (PARTS * 1024) + part * 1024;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, AUXL);
+      }
+      {  // epilogue inputs: this wave's quarter of the rows, lane = (row in quarter, 16-byte chunk of the 256-byte slice)
+        const int row = wave * 4 + (lane >> 4), ch = (lane & 15) ^ row;
+        const int i = 16 * j + row;
+        const int b = g + NG * i;
+        const int bs = b < Bt ? b : g;
+        char* eb = tb + ACTB + wave * 1024;
+        __builtin_amdgcn_global_load_lds((gptr_t)(carry_src + (long)bs * H + ch * 4), (lptr_t)eb, 16, 0, 0);
+        if constexpr (L0) {
+          const float* tp = a.table + (long)sTok[i < 128 ? i : 0] * 3 * H + c * 64 + ch * 4;
+          const float* zp = a.zproj + (long)bs * 3 * H + c * 64 + ch * 4;
+#pragma unroll
+          for (int gt = 0; gt < 3; ++gt) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(tp + gt * H), (lptr_t)(eb + G::CARRY_BYTES + gt * G::CARRY_BYTES), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(zp + gt * H), (lptr_t)(eb + G::CARRY_BYTES + G::GATE_BYTES + gt * G::CARRY_BYTES), 16, 0, 0);
+          }
+        }
       }
     };
     PG_STAMP(2);
     stage(0, 0);
-    int tok_next = 0;
-    if constexpr (L0) {
-      const int b0 = g + NG * lr;
-      tok_next = a.tok[o + (b0 < Bt ? b0 : g)];
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     PG_STAMP(3);
+    if (ntile > 1) stage(1, 1);                        // block-uniform
+    // Order inside the loop: after the barrier that ends tile j come the DMA of tile j+2 and only then the stores of
+    // tile j, so the wait at the end of tile j+1 ("tile j+2 has landed") leaves exactly those NS stores in flight: a
+    // store is waited for two tiles after its issue at the earliest (its acknowledgement takes 2-3 us).  Nothing in the
+    // loop loads from global memory into registers - hipcc would guard such a load with a wait for every older store.
     for (int j = 0; j < ntile; ++j) {
       const int buf = j & 1;
-      // epilogue inputs of this lane's sequence first, then the DMA of the next tile: the in-order vmcnt wait for the
-      // former must not drag the latter along
       const int b = g + NG * (16 * j + lr);
       const bool live = b < Bt;
-      const int bs = live ? b : g;                     // a valid row for the loads of finished sequences
-      const f32x4 hp4 = *reinterpret_cast<const f32x4*>((t == 0 ? a.h0_32 : carry) + (long)bs * H + u0);
-      f32x4 gi[3], gz[3];
-      if constexpr (L0) {
-        const float* tp = a.table + (long)tok_next * 3 * H + u0;
-        const float* zp = a.zproj + (long)bs * 3 * H + u0;
-#pragma unroll
-        for (int gt = 0; gt < 3; ++gt) {
-          gi[gt] = *reinterpret_cast<const f32x4*>(tp + gt * H);
-          gz[gt] = *reinterpret_cast<const f32x4*>(zp + gt * H);
-        }
-        if (j + 1 < ntile) {
-          const int bn = g + NG * (16 * (j + 1) + lr);
-          tok_next = a.tok[o + (bn < Bt ? bn : g)];
-        }
-      } else {
-#pragma unroll
-        for (int gt = 0; gt < 3; ++gt) {
-          gi[gt] = f32x4{bgi[gt][0], bgi[gt][1], bgi[gt][2], bgi[gt][3]};
-          gz[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-      if (j + 1 < ntile) stage(j + 1, buf ^ 1);        // block-uniform
+      const char* tb = sT + buf * TILEB;
       // ---- gates: acc[r], acc[z] over [h | x]; acc[hn] over h; acc[in] over x
       f32x4 acc[4];
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const char* A = sA + buf * G::TILE_BYTES + lr * (PARTS * 1024) + ((lq ^ lr) & 3) * 16;
+      const char* A = tb + lr * (PARTS * 1024) + ((lq ^ lr) & 3) * 16;
       const int hi = lr >> 2;
-      {
-        bf16x8 xc = *reinterpret_cast<const bf16x8*>(A + ((0 ^ hi) << 6)), xn = xc;
+      // LDS fragments are read in groups of 4 K-steps, two groups ahead of the MFMAs that consume them (the scheduling
+      // barriers keep hipcc from sinking the reads back to their uses: one exposed LDS latency per MFMA otherwise)
+      if (!(a.dbg & 2)) {
+        bf16x8 f[KS / 4][4];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          if (ks + 1 < KS) xn = *reinterpret_cast<const bf16x8*>(A + (((ks + 1) ^ hi) << 6));
-          acc[0] = mma16(wh[0][ks], xc, acc[0]);
-          acc[1] = mma16(wh[1][ks], xc, acc[1]);
-          acc[2] = mma16(wh[2][ks], xc, acc[2]);
-          xc = xn;
-        }
-      }
-      if constexpr (!L0) {
-        const char* Wn = sWin + (wave * 16 + lr) * ROWW + lq * 16;
-        bf16x8 xc = *reinterpret_cast<const bf16x8*>(A + 1024 + ((0 ^ hi) << 6)), xn = xc;
-        bf16x8 wc = *reinterpret_cast<const bf16x8*>(Wn), wn = wc;
+        for (int gk = 0; gk < 2; ++gk)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          if (ks + 1 < KS) {
-            xn = *reinterpret_cast<const bf16x8*>(A + 1024 + (((ks + 1) ^ hi) << 6));
-            wn = *reinterpret_cast<const bf16x8*>(Wn + (ks + 1) * 64);
+          for (int i = 0; i < 4; ++i) f[gk][i] = *reinterpret_cast<const bf16x8*>(A + (((gk * 4 + i) ^ hi) << 6));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int gk = 0; gk < KS / 4; ++gk) {
+          if (gk + 2 < KS / 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[gk + 2][i] = *reinterpret_cast<const bf16x8*>(A + ((((gk + 2) * 4 + i) ^ hi) << 6));
           }
-          acc[0] = mma16(wi[0][ks], xc, acc[0]);
-          acc[1] = mma16(wi[1][ks], xc, acc[1]);
-          acc[3] = mma16(wc, xc, acc[3]);
-          xc = xn; wc = wn;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int ks = gk * 4 + i;
+            acc[0] = mma16(wh[0][ks], f[gk][i], acc[0]);
+            acc[1] = mma16(wh[1][ks], f[gk][i], acc[1]);
+            acc[2] = mma16(wh[2][ks], f[gk][i], acc[2]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
-      // ---- epilogue on 4 units of sequence b
+      if constexpr (!L0) if (!(a.dbg & 2)) {
+        const char* Wn = sWin + (wave * 16 + lr) * ROWW + lq * 16;
+        bf16x8 fx[KS / 4][4], fw[KS / 4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          fx[0][i] = *reinterpret_cast<const bf16x8*>(A + 1024 + ((i ^ hi) << 6));
+          fw[0][i] = *reinterpret_cast<const bf16x8*>(Wn + i * 64);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int gk = 0; gk < KS / 4; ++gk) {
+          if (gk + 1 < KS / 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int ks = (gk + 1) * 4 + i;
+              fx[gk + 1][i] = *reinterpret_cast<const bf16x8*>(A + 1024 + ((ks ^ hi) << 6));
+              fw[gk + 1][i] = *reinterpret_cast<const bf16x8*>(Wn + ks * 64);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int ks = gk * 4 + i;
+            acc[0] = mma16(wi[0][ks], fx[gk][i], acc[0]);
+            acc[1] = mma16(wi[1][ks], fx[gk][i], acc[1]);
+            acc[3] = mma16(fw[gk][i], fx[gk][i], acc[3]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      // ---- epilogue on 4 units of sequence b; inputs from the tile's epilogue block (chunk q of row r sits at q ^ r)
+      const char* E = tb + ACTB + lr * 256 + (((wave * 4 + lq) ^ lr) << 4);
+      const f32x4 hp4 = *reinterpret_cast<const f32x4*>(E);
+      f32x4 g3[3];
+      if constexpr (L0) {
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt)
+          g3[gt] = *reinterpret_cast<const f32x4*>(E + G::CARRY_BYTES + gt * G::CARRY_BYTES) +
+                   *reinterpret_cast<const f32x4*>(E + G::CARRY_BYTES + G::GATE_BYTES + gt * G::CARRY_BYTES);
+      } else {
+#pragma unroll
+        for (int gt = 0; gt < 3; ++gt) g3[gt] = f32x4{bgi[gt][0], bgi[gt][1], bgi[gt][2], bgi[gt][3]};
+      }
       float r[4], z[4], n[4], hn[4], hp[4], h[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         hp[e] = hp4[e];
-        r[e] = sigmoidf_(gi[0][e] + gz[0][e] + acc[0][e]);
-        z[e] = sigmoidf_(gi[1][e] + gz[1][e] + acc[1][e]);
+        r[e] = sigmoidf_(g3[0][e] + acc[0][e]);
+        z[e] = sigmoidf_(g3[1][e] + acc[1][e]);
         hn[e] = acc[2][e] + bh[e];
-        n[e] = tanhf_(gi[2][e] + gz[2][e] + acc[3][e] + r[e] * hn[e]);
+        n[e] = tanhf_(g3[2][e] + acc[3][e] + r[e] * hn[e]);
         h[e] = (1.0f - z[e]) * n[e] + z[e] * hp[e];
       }
-      // the next tile must have landed before the barrier; waiting HERE (before this tile's stores are issued) keeps the
-      // write-through stores out of the wait - they drain under the next tile's MFMAs
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (live) {
-        *reinterpret_cast<f32x4*>(carry + (long)b * H + u0) = f32x4{h[0], h[1], h[2], h[3]};
+      // tile j+1 must have landed (this wave's DMAs; the barrier extends it to the others): everything older than the
+      // previous tile's stores.  The barrier also says that every wave is done reading tile j.
+      if (!(a.dbg & 1)) wait_all_but(j > 0 ? NS : 0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (j + 2 < ntile) stage(j + 2, buf);            // block-uniform
+      asm volatile("" ::: "memory");
+      {
+        const unsigned oob = 0x80000000u;              // beyond the descriptors' 2^31 - 1 records: the store is dropped
+        const bool st = live && !((a.dbg & 4) && h[0] != 12345.678f);
         const long s = (long)(o + b) * H + u0;
-        store_sc1_b64(r_hseq, (unsigned)(s * 2), to_bf16x4(h));
-        if (hdrop) {
+        const unsigned o2 = st ? (unsigned)(s * 2) : oob;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{h[0], h[1], h[2], h[3]}), r_carry,
+                                               (int)(st ? (unsigned)(((long)b * H + u0) * 4) : oob), 0, 0);
+        store_pub_b64<AUXL>(r_hseq, o2, to_bf16x4(h));
+        if (has_drop) {
           float hd[4], m[4];
           dropout_scale4(a.seed, l, t, b * a.b_mul + a.b_add, u0 >> 2, a.p_drop, inv_keep, m);
 #pragma unroll
           for (int e = 0; e < 4; ++e) hd[e] = h[e] * m[e];
-          store_sc1_b64(r_hdrop, (unsigned)(s * 2), to_bf16x4(hd));
+          store_pub_b64<AUXL>(r_hdrop, o2, to_bf16x4(hd));
         }
-        if (a.sv[l][0]) {
-          *reinterpret_cast<bf16x4*>(a.sv[l][0] + s) = to_bf16x4(r);
-          *reinterpret_cast<bf16x4*>(a.sv[l][1] + s) = to_bf16x4(z);
-          *reinterpret_cast<bf16x4*>(a.sv[l][2] + s) = to_bf16x4(n);
-          *reinterpret_cast<bf16x4*>(a.sv[l][3] + s) = to_bf16x4(hn);
-          *reinterpret_cast<bf16x4*>(a.sv[l][4] + s) = to_bf16x4(hp);
+        if (has_sv) {
+          store_pub_b64<0>(pg_make_rsrc(a.sv[l][0]), o2, to_bf16x4(r));
+          store_pub_b64<0>(pg_make_rsrc(a.sv[l][1]), o2, to_bf16x4(z));
+          store_pub_b64<0>(pg_make_rsrc(a.sv[l][2]), o2, to_bf16x4(n));
+          store_pub_b64<0>(pg_make_rsrc(a.sv[l][3]), o2, to_bf16x4(hn));
+          store_pub_b64<0>(pg_make_rsrc(a.sv[l][4]), o2, to_bf16x4(hp));
         }
       }
       if (j == 0) PG_STAMP(4);
@@ -288,29 +364,44 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     PG_STAMP(6);
-    if (tid == 0) __hip_atomic_fetch_add(cnt_own, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      if constexpr (AUXL == 0) {   // plain payload stores: lane-0 agent release (L2 write-back) before the arrival
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __hip_atomic_fetch_add(cnt_own, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     PG_STAMP(7);
   }
 }
 
-template <int H>
+template <int H, int AUXL>
 __global__ __launch_bounds__(256) void dec_fwd_persist_kernel(DecFwdPersist a, Sched sd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int g = blockIdx.x % a.NG, k = blockIdx.x / a.NG;   // blockIdx % 8 labels the XCD: a group's workgroups share one
   const int l = k / DecGeo<H>::NCU, c = k % DecGeo<H>::NCU;
-  if (l == 0) dec_fwd_body<H, true>(a, sd, g, l, c, smem);
-  else dec_fwd_body<H, false>(a, sd, g, l, c, smem);
+  if (l == 0) dec_fwd_body<H, true, AUXL>(a, sd, g, l, c, smem);
+  else dec_fwd_body<H, false, AUXL>(a, sd, g, l, c, smem);
 }
 
 unsigned long long* g_stamps = nullptr;
+int g_stamps_which = 0;            // 0: forward kernel, 1: BPTT kernel
 int* g_fail_host = nullptr;        // pinned mirror of the sticky give-up word
 unsigned* g_fail_dev = nullptr;   // never cleared: one timed-out launch condemns the process
 
 }  // namespace
 
-bool dec_persist_supported(int H, int L, int B) { return H == 512 && L >= 1 && L * (H / 64) * 8 <= 256 && B >= 1; }
+// B <= 1024: a group owns at most 128 sequences (the token block in LDS of layer 0 is sized for that)
+bool dec_persist_supported(int H, int L, int B) { return H == 512 && L >= 1 && L * (H / 64) * 8 <= 256 && B >= 1 && B <= 1024; }
 
 int persist_poll_failure() { return g_fail_host ? *reinterpret_cast<volatile int*>(g_fail_host) : 0; }
+
+// experiment switch PG_DMA_PLAIN=1: the LDS-DMA loads of published rows use the default cache policy (they sit behind the
+// step's agent acquire, which makes plain loads a valid consumer form) instead of sc1
+bool persist_dma_plain() {
+  static const bool v = getenv("PG_DMA_PLAIN") && atoi(getenv("PG_DMA_PLAIN")) != 0;
+  return v;
+}
 
 int persist_fail_words(unsigned** dev) {
   if (!g_fail_host) {
@@ -334,11 +425,14 @@ int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t
   using G = DecGeo<512>;
   a.NG = 8;   // one group per XCD
   PG_TRY(persist_fail_words(&a.fail));
-  a.stamps = g_stamps;
+  a.stamps = g_stamps_which == 0 ? g_stamps : nullptr;
+  a.dbg = getenv("PG_PERSIST_DBG") ? atoi(getenv("PG_PERSIST_DBG")) : 0;
   PG_CHECK_HIP(hipMemsetAsync(a.sync, 0, PG_PERSIST_SYNC_WORDS * sizeof(unsigned), stream));
   static bool attr_done = false;
   if (!attr_done) {
-    PG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fwd_persist_kernel<512>),
+    PG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fwd_persist_kernel<512, AUX_SC1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM));
+    PG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fwd_persist_kernel<512, 0>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM));
     attr_done = true;
   }
@@ -353,14 +447,21 @@ int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t
     PG_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
   }
   PG_REQUIRE(grid <= n_cu, "dec_fwd_persist: %d workgroups cannot be co-resident on %d CUs", grid, n_cu);
-  hipLaunchKernelGGL((dec_fwd_persist_kernel<512>), dim3(grid), dim3(256), (size_t)G::SMEM, stream, a, sd);
+  if (persist_dma_plain())
+    hipLaunchKernelGGL((dec_fwd_persist_kernel<512, 0>), dim3(grid), dim3(256), (size_t)G::SMEM, stream, a, sd);
+  else
+    hipLaunchKernelGGL((dec_fwd_persist_kernel<512, AUX_SC1>), dim3(grid), dim3(256), (size_t)G::SMEM, stream, a, sd);
   PG_CHECK_LAUNCH();
   PG_TRY(persist_fail_mirror(stream));
   return PG_OK;
 }
 
-// development aid (tools/persist_stamps.py): device buffer of 8 + 64 u64 words; word 0 = layer to trace
-extern "C" __attribute__((visibility("default"))) int pg_persist_stamps(void* buf) {
+unsigned long long* persist_stamps_for(int which) { return g_stamps_which == which ? g_stamps : nullptr; }
+
+// development aid (tools/persist_stamps.py): device buffer of 8 + 64 u64 words; word 0 = layer to trace;
+// which = 0 traces the forward kernel, 1 the BPTT kernel
+extern "C" __attribute__((visibility("default"))) int pg_persist_stamps(void* buf, int which) {
   g_stamps = static_cast<unsigned long long*>(buf);
+  g_stamps_which = which;
   return PG_OK;
 }

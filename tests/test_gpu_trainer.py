@@ -49,7 +49,7 @@ def test_fused_real_dims_trajectory(golden_dir):
 
 def test_dropout_mask_consistent_between_forward_and_backward():
     """Train-mode dropout: the gradient must be that of the SAME masked network.  Checked by finite differences of the
-    fused loss along a random direction (the Philox mask is a pure function of (seed, layer, t, row, col))."""
+    fused loss along a random direction (the mask is a counter hash, a pure function of (seed, layer, t, row, col))."""
     from polygon_amd.vae.vae_trainer import FusedClipAdam
     model, _ = build_model(TINY, 5, "fp32", d_dropout=0.3)
     model.train()
