@@ -36,7 +36,8 @@ def traffic(db_f, db_w, out_json, dtype):
     out = {}
     for k in sorted(set(F) | set(W)):
         short = k
-        for tag in ("gru_bwd2_diag_kernel", "gru_fwd2_diag_kernel", "gru_bwd2_kernel", "gru_fwd2_kernel", "gemm_tn_kernel",
+        for tag in ("dec_bwd_persist_kernel", "dec_fwd_persist_kernel", "enc_bwd_persist_kernel", "enc_fwd_persist_kernel",
+                    "gru_bwd2_diag_kernel", "gru_fwd2_diag_kernel", "gru_bwd2_kernel", "gru_fwd2_kernel", "gemm_tn_kernel",
                     "gemm_nt_kernel", "colsum_kernel", "ce_kernel", "adam_kernel", "sample_head_kernel"):
             if tag in k:
                 short = tag
