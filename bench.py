@@ -117,8 +117,9 @@ def roofline_recurrence(dtype):
                     "LDS fragment bandwidth (every wave reads the whole 16-row tile), not by MFMA throughput: DESIGN.md 3"}
 
 
-def cpu_baseline(n_strings=192):
-    """The CPU oracle (numpy restatement of the reference's torch CPU path), one fwd+bwd+clip+Adam step, fp32."""
+def cpu_baseline(n_strings=1024):
+    """The CPU oracle (numpy restatement of the reference's torch CPU path), one fwd+bwd+clip+Adam step, fp32, on ONE
+    batch of the benchmark's size (bounded sample: ~5-15 s of CPU work on the GPU box's host cores)."""
     from oracle import vae_oracle as O
     try:
         import threadpoolctl

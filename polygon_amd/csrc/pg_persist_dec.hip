@@ -168,6 +168,8 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
       case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
       case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
       case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+      case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
       default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
   };
@@ -228,11 +230,17 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
       }
     };
     PG_STAMP(2);
+    // both buffers are free at the start of a step: tiles 0 and 1 are requested together, the first wait leaves tile 1's
+    // ND instructions in flight
+    constexpr int ND = RP_WAVE + 1 + (L0 ? 6 : 0);     // DMA instructions per wave and tile
+    static_assert(ND == 9 || ND == 11, "wait_all_but has no case for this tile");
     stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    PG_STAMP(3);
     if (ntile > 1) stage(1, 1);                        // block-uniform
+    if (a.dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else wait_all_but(ntile > 1 ? ND : 0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    PG_STAMP(3);
     // Order inside the loop: after the barrier that ends tile j come the DMA of tile j+2 and only then the stores of
     // tile j, so the wait at the end of tile j+1 ("tile j+2 has landed") leaves exactly those NS stores in flight: a
     // store is waited for two tiles after its issue at the earliest (its acknowledgement takes 2-3 us).  Nothing in the

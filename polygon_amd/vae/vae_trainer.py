@@ -66,6 +66,20 @@ class FusedClipAdam(torch.optim.Optimizer):
                                            _lib.ptr(self.gnorm), _lib.stream_ptr()), "pg_clip_adam")
         eng.invalidate()
 
+    # ---- optimiser state for checkpoint / resume (no counterpart in the reference, which saves weights only:
+    # polygon/utils/utils.py:90-110) ------------------------------------------------------------
+    def train_state(self):
+        return {"exp_avg": self.exp_avg.detach().cpu(), "exp_avg_sq": self.exp_avg_sq.detach().cpu(),
+                "n_steps": self.n_steps, "lr": self.param_groups[0]["lr"], "n_params": int(self.exp_avg.numel())}
+
+    def load_train_state(self, st):
+        if int(st["n_params"]) != int(self.exp_avg.numel()):
+            raise ValueError("optimiser state holds %d values, the model has %d" % (st["n_params"], self.exp_avg.numel()))
+        self.exp_avg.copy_(st["exp_avg"])
+        self.exp_avg_sq.copy_(st["exp_avg_sq"])
+        self.n_steps = int(st["n_steps"])
+        self.param_groups[0]["lr"] = float(st["lr"])
+
 
 class VAETrainer:
     def __init__(self, model, **kwargs):
@@ -87,6 +101,9 @@ class VAETrainer:
         self.lr_n_restarts = 6
         self.lr_n_mult = 1
         self.lr_end = 0.0003
+        # additions (off by default = the reference's behaviour): write '<stem>_<epoch>.state.pt' (optimiser moments, step
+        # count, epoch, scheduler position) next to every weight checkpoint; fit(resume_from=...) continues from one
+        self.save_train_state = False
         self.__dict__.update(kwargs)
         self.device = self.model.device
 
@@ -193,7 +210,7 @@ class VAETrainer:
         """Adam(lr_start) as vae_trainer.py:217-218; fused when the model lives on the GPU (always, in practice)."""
         return FusedClipAdam(self.model, lr=self.lr_start, clip_grad=self.clip_grad)
 
-    def _train(self, train_loader, val_loader=None, n_epoch=None, save_frequency=None):
+    def _train(self, train_loader, val_loader=None, n_epoch=None, save_frequency=None, resume_from=None):
         if n_epoch is None:
             n_epoch = self._n_epoch()
         if save_frequency is None:
@@ -205,7 +222,15 @@ class VAETrainer:
         self.model.zero_grad()
         rank, _ = world_info()
         width = len(str(n_epoch))
-        for epoch in range(n_epoch):
+        first_epoch = 0
+        if resume_from is not None:   # the weights themselves come from load_model(); this restores the rest
+            st = torch.load(resume_from, map_location="cpu", weights_only=True)
+            optimizer.load_train_state(st["optimizer"])
+            for _ in range(int(st["epoch"]) + 1):
+                lr_annealer.step()    # the schedule is a pure function of the epoch count (vae_misc.py)
+            optimizer.param_groups[0]["lr"] = float(st["lr_next"])
+            first_epoch = int(st["epoch"]) + 1
+        for epoch in range(first_epoch, n_epoch):
             kl_weight = kl_annealer(epoch)
             postfix = self._train_epoch(epoch, train_loader, kl_weight, optimizer,
                                         label='Training   (epoch #{})'.format(str(epoch).zfill(width)))
@@ -220,8 +245,12 @@ class VAETrainer:
                 save_model(self.model, output_path='{path}_{epoch:03d}.pt'.format(
                     path=os.path.splitext(self.model_save)[0], epoch=epoch))
             lr_annealer.step()
+            if self.save_train_state and (self.model_save is not None) and (epoch % save_frequency == 0) and rank == 0:
+                torch.save({"epoch": epoch, "optimizer": optimizer.train_state(),
+                            "lr_next": optimizer.param_groups[0]["lr"]},
+                           '{path}_{epoch:03d}.state.pt'.format(path=os.path.splitext(self.model_save)[0], epoch=epoch))
 
-    def fit(self, train_data, val_data=None, n_epoch=None, batch_size=None, save_frequency=None):
+    def fit(self, train_data, val_data=None, n_epoch=None, batch_size=None, save_frequency=None, resume_from=None):
         rank, _ = world_info()
         if self.log_file is not None and rank == 0:
             lines = ["Training Parameters:", "\n".join("{}: {}".format(k, v) for k, v in self.__dict__.items()),
@@ -230,6 +259,6 @@ class VAETrainer:
                 handle.write("\n".join(lines) + "\n")
         train_loader = self.get_dataloader(train_data, batch_size=batch_size, shuffle=True)
         val_loader = None if val_data is None else self.get_dataloader(val_data, batch_size=batch_size, shuffle=False)
-        self._train(train_loader, val_loader, n_epoch=n_epoch, save_frequency=save_frequency)
+        self._train(train_loader, val_loader, n_epoch=n_epoch, save_frequency=save_frequency, resume_from=resume_from)
         if self.model_save is not None and rank == 0:
             save_model(self.model, output_path=self.model_save)

@@ -99,3 +99,42 @@ def test_trainer_fit_runs_and_learns(tmp_path):
     m2 = load_model(VAE, str(tmp_path / "m.pt"), "cuda", model_params=dict(q_d_h=32, d_z=16, d_d_h=64, d_n_layers=3))
     for (k, a), (_, b) in zip(model.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a.cpu(), b.cpu()), k
+
+
+def test_resume_from_train_state(tmp_path):
+    """optimiser moments / step count / schedule position are checkpointed next to the weights and a resumed
+    fit continues where the first one stopped (same Adam state, next epoch index, same learning rate)."""
+    from polygon_amd.utils.utils import load_model
+    from polygon_amd.vae.vae_model import VAE
+    from polygon_amd.vae.vae_trainer import FusedClipAdam, VAETrainer
+    torch.manual_seed(0)
+    model, _ = build_model(TINY, 3, "fp32")
+    data = O.synthetic_smiles(64, seed=2)
+    kw = dict(n_batch=32, n_epoch=4, kl_start=0, kl_w_start=0.0, kl_w_end=0.1, lr_start=3e-3, lr_end=1e-4, lr_n_period=4,
+              lr_n_restarts=1, save_frequency=1, save_train_state=True)
+    made = []
+    orig = VAETrainer._make_optimizer
+
+    def spy(self):
+        made.append(orig(self))
+        return made[-1]
+    VAETrainer._make_optimizer = spy
+    try:
+        tr = VAETrainer(model, model_save=str(tmp_path / "a.pt"), log_file=str(tmp_path / "a.csv"), **kw)
+        tr.fit(list(data), n_epoch=2)
+        st = torch.load(tmp_path / "a_001.state.pt", weights_only=True)
+        assert st["epoch"] == 1 and st["optimizer"]["n_steps"] == 4
+        assert torch.equal(st["optimizer"]["exp_avg"], made[0].exp_avg.cpu())
+        m2 = load_model(VAE, str(tmp_path / "a_001.pt"), "cuda", model_params=dict(q_d_h=32, d_z=16, d_d_h=64, d_n_layers=3))
+        tr2 = VAETrainer(m2, model_save=str(tmp_path / "b.pt"), log_file=str(tmp_path / "b.csv"), **kw)
+        tr2.fit(list(data), n_epoch=4, resume_from=str(tmp_path / "a_001.state.pt"))
+    finally:
+        VAETrainer._make_optimizer = orig
+    assert made[1].n_steps == 8                      # 4 restored + 2 epochs x 2 batches
+    rows = [l.strip().split(",") for l in open(tmp_path / "b.csv") if l.strip().endswith("Train")]
+    assert [int(r[0]) for r in rows] == [2, 3]
+    # epoch 2 ran at the learning rate the uninterrupted schedule has there
+    import math
+    lr2 = 1e-4 + (3e-3 - 1e-4) * (1 + math.cos(math.pi * 3 / 4)) / 2   # the scheduler's constructor already stepped once
+    assert abs(float(rows[0][2]) - lr2) <= 1e-9 + 1e-6 * lr2
+    assert os.path.exists(tmp_path / "b_003.state.pt")
