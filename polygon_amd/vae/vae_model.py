@@ -507,6 +507,22 @@ class VAE(nn.Module):
             smiles = self.sample(z.shape[0], z=z, multinomial=True)
         return smiles
 
+    @torch.no_grad()
+    def encode_smiles(self, smiles_list, batch_size=1024):
+        """mu [n, d_z] of MANY SMILES in INPUT order: the batched form of ``encode(collate([s]))`` that the reference's
+        LatentDistance scorer calls once per molecule (polygon/utils/custom_scoring_fcn.py:165-169).
+        Strings are length-sorted per chunk as the kernels require and the rows are put back in the caller's order."""
+        n = len(smiles_list)
+        out = torch.empty(n, self.q_mu.out_features, device=self.device)
+        order = sorted(range(n), key=lambda i: len(smiles_list[i]), reverse=True)    # stable, like the reference collate
+        collate = self.get_collate_fn()
+        for a in range(0, n, batch_size):
+            idx = order[a:a + batch_size]
+            batch = collate([smiles_list[i] for i in idx])                            # already sorted: order is kept
+            mu = self.encode(batch)
+            out[torch.tensor(idx, device=out.device)] = mu
+        return out
+
     def get_latent_space_from_smiles(self, smiles):
         x = self.string2tensor(smiles)
         z, kl_loss = self.forward_encoder([x])

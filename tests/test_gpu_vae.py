@@ -184,3 +184,27 @@ def test_profile_hook_counts_recurrence_launches():
     ms, n, fl, seg = ctypes.c_double(), ctypes.c_long(), ctypes.c_double(), ctypes.c_int()
     _lib.check(L.pg_profile_read(1, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(seg)))
     assert n.value == 0 and seg.value == 0
+
+
+def test_batched_latent_distance_matches_per_molecule():
+    """the batched encode / LatentDistance raw scores equal the reference's one-molecule-at-a-time loop
+    (custom_scoring_fcn.py:165-178) and the oracle's mu."""
+    from polygon_amd.vae.latent_distance import encode_targets, latent_distance_scores
+    model, P = build_model(REAL, 13, "fp32")
+    model.eval()
+    targets = list(O.synthetic_smiles(7, seed=21))
+    mols = list(O.synthetic_smiles(37, seed=22)) + ["C", "CCl", ""]
+    zt = encode_targets(model, list(targets))
+    for agg, n_top in (("mean", None), ("min", 3), ("max", 5)):
+        got = latent_distance_scores(model, mols, zt, n_top=n_top, agg=agg, batch_size=16)
+        k = len(targets) if n_top is None else n_top
+        for i in (0, 5, 36, 37, 39):
+            z = model.encode(model.get_collate_fn()([mols[i]]))
+            norm = torch.norm(zt - z, dim=1).sort()[0][:k].cpu().numpy()
+            ref = {"mean": norm.mean(), "max": norm.max(), "min": norm.min()}[agg]
+            assert abs(got[i] - ref) <= 1e-4 * max(1.0, abs(ref)), (agg, i, got[i], ref)
+    mu = model.encode_smiles(mols, batch_size=16).cpu().numpy()
+    eps = np.zeros((len(mols), REAL["Dz"]))
+    order = sorted(range(len(mols)), key=lambda i: len(mols[i]), reverse=True)
+    enc, _ = O.vae_forward(P, O.collate([mols[i] for i in order]), eps)
+    assert rel_err(mu[order], enc["mu"]) <= 1e-3
