@@ -61,8 +61,40 @@ def traffic(db_f, db_w, out_json, dtype):
                    dtype: out}, f, indent=1, sort_keys=True)
 
 
+def counters(dbs, out_json, note):
+    """Per-kernel averages (per launch, summed over the device's shader engines as rocprofv3 reports them) of every counter
+    found in the given --pmc result databases; kernels matched by the names of interest only."""
+    tags = ("dec_bwd_persist_kernel", "dec_fwd_persist_kernel", "enc_bwd_persist_kernel", "enc_fwd_persist_kernel",
+            "gemm_tn_kernel", "gemm_nt_kernel", "ce_kernel", "adam_kernel")
+    out = {}
+    for db in dbs:
+        c = sqlite3.connect(db)
+        for kname, cname, n, v in c.execute(
+                "select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name"):
+            for tag in tags:
+                if tag in kname:
+                    e = out.setdefault(tag, {})
+                    e[cname] = v
+                    e["launches_" + cname] = n
+    for e in out.values():   # derived ratios (MI355X_MICROARCH.md counter table)
+        if "SQ_WAVE_CYCLES" in e and e["SQ_WAVE_CYCLES"]:
+            w = e["SQ_WAVE_CYCLES"]
+            for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
+                      "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM"):
+                if k in e:
+                    e["frac_of_wave_cycles_" + k] = e[k] / w
+        # SQ_WAVE_CYCLES counts quad-cycles (4 clocks); the persistent kernels hold ONE wave per SIMD, so 4 * WAVE_CYCLES is
+        # their SIMD time and MFMA_BUSY / that is the matrix-pipe utilisation.  Not valid at higher occupancy.
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in e and e.get("SQ_WAVE_CYCLES"):
+            e["mfma_util_if_one_wave_per_simd"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * e["SQ_WAVE_CYCLES"])
+    with open(out_json, "w") as f:
+        json.dump({"_how": note, "bf16": out}, f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "counters":
+        counters(sys.argv[4:], sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "rocprofv3 --kernel-trace --stats")
     else:
         traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
