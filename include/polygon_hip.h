@@ -132,6 +132,15 @@ PG_API int pg_bench_gru(int dtype, int which, int rows, int H, void* ws, size_t 
 PG_API int pg_profile_enable(int on);
 PG_API int pg_profile_read(int which, double* total_ms, long* launches, double* flop, int* segments);
 
+/* Deferred weight gradients (no reference counterpart; off by default).  While on, pg_decoder_bwd enqueues the decoder's
+ * large weight-gradient GEMMs on a library-owned side stream (created on first use, never destroyed) so that they run
+ * beside the following pg_encoder_bwd, a latency-bound kernel on a quarter of the CUs.  The decoder weight gradients are
+ * complete, in the order of the caller's stream, after the next pg_encoder_bwd or pg_clip_adam on that stream, or after
+ * pg_deferred_join(stream) (e.g. the stream a gradient all-reduce will run on).  A caller that reads the gradients
+ * without any of the three must leave this off.  pg_defer_weight_grads returns the previous setting (on < 0: query). */
+PG_API int pg_defer_weight_grads(int on);
+PG_API int pg_deferred_join(void* stream);
+
 /* Test / A-B hook (no reference counterpart): the recurrences run as persistent kernels where the shape is covered
  * (bf16, Hq = 256, Hd = 512); mask bits force the per-step kernels instead: 1 encoder, 2 decoder forward, 4 decoder BPTT.
  * mask < 0 only queries.  Returns the previous mask.  The environment variable PG_NO_PERSIST sets the initial mask. */

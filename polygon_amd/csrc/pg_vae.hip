@@ -193,6 +193,52 @@ static int check_persist() {
   return PG_OK;
 }
 
+// ---- deferred weight gradients: the decoder's large weight-gradient GEMMs run on a library-owned side stream, beside the
+// encoder BPTT (a row-resident kernel on 64 of the 256 CUs, latency-bound).  Never beside the group-persistent decoder
+// kernels, whose workgroups must all be co-resident.  Joined at the end of pg_encoder_bwd, in pg_clip_adam and by
+// pg_deferred_join.
+static int g_defer = 0;
+static int g_defer_dev = -1;
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
+static bool g_defer_pending = false;
+extern "C" int pg_defer_weight_grads(int on) {
+  const int old = g_defer;
+  if (on >= 0) g_defer = on ? 1 : 0;
+  return old;
+}
+static int defer_fork(hipStream_t st, hipStream_t* side) {   // *side = stream for the deferred GEMMs (st itself when off)
+  *side = st;
+  if (!g_defer) return PG_OK;
+  int dev = 0;
+  PG_CHECK_HIP(hipGetDevice(&dev));
+  if (!g_side) {
+    PG_CHECK_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+    PG_CHECK_HIP(hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming));
+    PG_CHECK_HIP(hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming));
+    g_defer_dev = dev;
+  }
+  if (dev != g_defer_dev) return PG_OK;   // one process per GPU is the model; another device simply does not defer
+  PG_CHECK_HIP(hipEventRecord(g_ev_fork, st));
+  PG_CHECK_HIP(hipStreamWaitEvent(g_side, g_ev_fork, 0));
+  *side = g_side;
+  return PG_OK;
+}
+static int defer_done(hipStream_t side, hipStream_t st) {
+  if (side == st) return PG_OK;
+  PG_CHECK_HIP(hipEventRecord(g_ev_join, side));
+  g_defer_pending = true;
+  return PG_OK;
+}
+static int defer_join(hipStream_t st, bool clear) {
+  if (g_defer_pending) {
+    PG_CHECK_HIP(hipStreamWaitEvent(st, g_ev_join, 0));
+    if (clear) g_defer_pending = false;
+  }
+  return PG_OK;
+}
+extern "C" int pg_deferred_join(void* stream) { return defer_join((hipStream_t)stream, false); }
+
 static bool use_persistent_dec(int H, int L, int B) { return !(persist_off_mask() & 2) && dec_persist_supported(H, L, B); }
 static bool use_persistent_dec_bwd(int H, int L, int B) { return !(persist_off_mask() & 4) && dec_persist_supported(H, L, B); }
 
@@ -543,41 +589,47 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
     PG_TRY(launch_gru_bwd_diag<T>(dg, st));
   }
   prof_end(1, pslot, st, sd.T + L, pflop);
+  // The dz path first (it is what the encoder BPTT waits for); the large weight-gradient GEMMs last - on the side stream
+  // when deferral is on (they then run beside pg_encoder_bwd).
+  {
+    T* dGI = at<T>(ws, w.b_dGI_l[0]);
+    // layer 0 input = [x_emb[token] ; z]: token half through the gather table, z half per sequence
+    T* oh = at<T>(ws, w.b_onehot);
+    float* dT = at<float>(ws, w.b_dT);
+    hipLaunchKernelGGL(onehot_kernel<T>, dim3(ew_blocks(Nd * Vp)), dim3(256), 0, st, at<int>(ws, w.dec_tok), Nd, Vp, oh);
+    PG_CHECK_LAUNCH();
+    PG_CHECK_HIP(hipMemsetAsync(dT, 0, (size_t)Vp * 3 * Hd * 4, st));
+    PG_TRY(launch_gemm_tn<T>(oh, Vp, dGI, 3 * Hd, Vp, 3 * Hd, (int)Nd, dT, 3 * Hd, 1.0f, nullptr, st, nullptr,
+                             grads + po.dec_bih[0]));
+    // d x_emb[v,e] += sum_g dT[v,g] W_ih0[g,e] ; d W_ih0[g,e] += sum_v dT[v,g] x_emb[v,e]
+    PG_TRY(small_gemm(dT, 3 * Hd, 1, params + po.dec_wih[0], E + Dz, 1, V, E, 3 * Hd, grads + po.x_emb, E, d->pad, st));
+    PG_TRY(small_gemm(dT, 1, 3 * Hd, params + po.x_emb, E, 1, 3 * Hd, E, V, grads + po.dec_wih[0], E + Dz, -1, st));
+    float* dzp = at<float>(ws, w.b_dzproj);
+    T* dzp_op = at<T>(ws, w.b_dzproj_op);
+    hipLaunchKernelGGL(rowseg_sum_kernel<T>, dim3(cdiv(3 * Hd, 256), B), dim3(256), 0, st, dGI, at<int>(ws, w.dec_off), sd.T,
+                       3 * Hd, dzp, dzp_op);
+    PG_CHECK_LAUNCH();
+    PG_TRY(launch_gemm_tn<T>(dzp_op, 3 * Hd, at<T>(ws, w.d_zop), Dz, 3 * Hd, Dz, B, grads + po.dec_wih[0] + E, E + Dz, 1.0f,
+                             nullptr, st));
+    GemmEpi<T> e;
+    e.C32 = dz; e.ldc = Dz;
+    PG_TRY(launch_gemm_nt<T>(dzp_op, 3 * Hd, at<T>(shadow, so.wih0zT), 3 * Hd, B, Dz, 3 * Hd, e, st));
+  }
+  hipStream_t sg = st;
+  PG_TRY(defer_fork(st, &sg));
   for (int l = L - 1; l >= 0; --l) {
     T* dGI = at<T>(ws, w.b_dGI_l[l]);
     T* dGH = at<T>(ws, w.b_dGH_l[l]);
-    // weight / bias gradients of the layer (batched over all packed rows)
     // weight gradients of the layer, batched over all packed rows; the bias gradients (column sums of dGH / dGI) ride along
     PG_TRY(launch_gemm_tn<T>(dGH, 3 * Hd, at<T>(ws, w.d_sv[l][4]), Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_whh[l], Hd, 1.0f,
-                             nullptr, st, grads + po.dec_bhh[l]));
+                             nullptr, sg, grads + po.dec_bhh[l]));
     if (l > 0) {
       const T* X = drop ? at<T>(ws, w.d_hdrop[l - 1]) : at<T>(ws, w.d_hseq[l - 1]);
-      PG_TRY(launch_gemm_tn<T>(dGI, 3 * Hd, X, Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_wih[l], Hd, 1.0f, nullptr, st,
+      PG_TRY(launch_gemm_tn<T>(dGI, 3 * Hd, X, Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_wih[l], Hd, 1.0f, nullptr, sg,
                                grads + po.dec_bih[l]));
-    } else {
-      // layer 0 input = [x_emb[token] ; z]: token half through the gather table, z half per sequence
-      T* oh = at<T>(ws, w.b_onehot);
-      float* dT = at<float>(ws, w.b_dT);
-      hipLaunchKernelGGL(onehot_kernel<T>, dim3(ew_blocks(Nd * Vp)), dim3(256), 0, st, at<int>(ws, w.dec_tok), Nd, Vp, oh);
-      PG_CHECK_LAUNCH();
-      PG_CHECK_HIP(hipMemsetAsync(dT, 0, (size_t)Vp * 3 * Hd * 4, st));
-      PG_TRY(launch_gemm_tn<T>(oh, Vp, dGI, 3 * Hd, Vp, 3 * Hd, (int)Nd, dT, 3 * Hd, 1.0f, nullptr, st, nullptr,
-                               grads + po.dec_bih[0]));
-      // d x_emb[v,e] += sum_g dT[v,g] W_ih0[g,e] ; d W_ih0[g,e] += sum_v dT[v,g] x_emb[v,e]
-      PG_TRY(small_gemm(dT, 3 * Hd, 1, params + po.dec_wih[0], E + Dz, 1, V, E, 3 * Hd, grads + po.x_emb, E, d->pad, st));
-      PG_TRY(small_gemm(dT, 1, 3 * Hd, params + po.x_emb, E, 1, 3 * Hd, E, V, grads + po.dec_wih[0], E + Dz, -1, st));
-      float* dzp = at<float>(ws, w.b_dzproj);
-      T* dzp_op = at<T>(ws, w.b_dzproj_op);
-      hipLaunchKernelGGL(rowseg_sum_kernel<T>, dim3(cdiv(3 * Hd, 256), B), dim3(256), 0, st, dGI, at<int>(ws, w.dec_off), sd.T,
-                         3 * Hd, dzp, dzp_op);
-      PG_CHECK_LAUNCH();
-      PG_TRY(launch_gemm_tn<T>(dzp_op, 3 * Hd, at<T>(ws, w.d_zop), Dz, 3 * Hd, Dz, B, grads + po.dec_wih[0] + E, E + Dz, 1.0f,
-                               nullptr, st));
-      GemmEpi<T> e;
-      e.C32 = dz; e.ldc = Dz;
-      PG_TRY(launch_gemm_nt<T>(dzp_op, 3 * Hd, at<T>(shadow, so.wih0zT), 3 * Hd, B, Dz, 3 * Hd, e, st));
     }
   }
+  PG_TRY(defer_done(sg, st));
   // decoder_lat: h0 = W z + b feeds every layer
   T* dh0_op = at<T>(ws, w.b_dh0_op);
   if (!persist) PG_TRY(convert_to<T>(dh0, dh0_op, (long)B * Hd, st));
@@ -675,6 +727,7 @@ static int encoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   PG_TRY(launch_gemm_tn<T>(oh, Vp, dGI, 3 * Hq, Vp, 3 * Hq, (int)Ne, dT, 3 * Hq, 1.0f, nullptr, st, nullptr, grads + po.enc_bih));
   PG_TRY(small_gemm(dT, 3 * Hq, 1, params + po.enc_wih, E, 1, V, E, 3 * Hq, grads + po.x_emb, E, d->pad, st));
   PG_TRY(small_gemm(dT, 1, 3 * Hq, params + po.x_emb, E, 1, 3 * Hq, E, V, grads + po.enc_wih, E, -1, st));
+  PG_TRY(defer_join(st, false));   // the decoder's deferred weight gradients: complete in stream order from here on
   return PG_OK;
 }
 
@@ -698,6 +751,7 @@ extern "C" int pg_clip_adam(long n, float* params, const float* grads, float* ex
   PG_REQUIRE(n > 0 && params && grads && exp_avg && exp_avg_sq && scratch, "pg_clip_adam: NULL buffer");
   PG_REQUIRE(step >= 1, "pg_clip_adam: step must be >= 1");
   hipStream_t st = (hipStream_t)stream;
+  PG_TRY(defer_join(st, true));
   hipLaunchKernelGGL(sumsq_kernel, dim3(PG_SUMSQ_BLOCKS), dim3(256), 0, st, grads, n, scratch);
   PG_CHECK_LAUNCH();
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);

@@ -255,10 +255,16 @@ class _Engine:
         grads.zero_()
         self.encoder_fwd(ws, batch, eps, dp, 1, z, None, None, scal[0:1])
         self.decoder_fwd(ws, batch, z, dp, p_drop, seed, 0, 1, scal[1:2])
-        self.decoder_bwd(ws, batch, dp, p_drop, seed, 0, 1.0, None, grads, dz)
-        if comm is not None:
-            comm.start_decoder_bucket(grads, self.decoder_param_start())
-        self.encoder_bwd(ws, batch, dp, dz, float(kl_weight), None, grads)
+        # the decoder's large weight-gradient GEMMs run beside the encoder BPTT (side stream inside the library; joined
+        # at the end of pg_encoder_bwd).  Under data parallelism the decoder bucket's all-reduce needs them first.
+        old = L.pg_defer_weight_grads(0 if comm is not None else 1)
+        try:
+            self.decoder_bwd(ws, batch, dp, p_drop, seed, 0, 1.0, None, grads, dz)
+            if comm is not None:
+                comm.start_decoder_bucket(grads, self.decoder_param_start())
+            self.encoder_bwd(ws, batch, dp, dz, float(kl_weight), None, grads)
+        finally:
+            L.pg_defer_weight_grads(old)
         if comm is not None:
             comm.finish(grads, self.decoder_param_start())
         return scal[0], scal[1]
