@@ -32,6 +32,23 @@ constexpr int AUX_SC1 = 16;
 __device__ __forceinline__ f32x4 mma16(const bf16x8& w, const bf16x8& x, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0);
 }
+// The same MFMA with its stationary weight operand taken straight from an accumulation register (AGPR).  A wave of these
+// kernels holds 320 registers of weight fragments, more than the 256 architectural VGPRs: left to itself hipcc parks
+// them in AGPRs and copies each fragment back with four v_accvgpr_read (plus a hazard nop) in front of every MFMA.
+// The instruction accepts an AGPR for srcA, so the "a" constraint removes ~200 VALU instructions per tile.  Inline asm is
+// opaque to hipcc's hazard recognizer: the caller puts PG_MFMA_DRAIN between the last MFMA and the first VALU read of an
+// accumulator (matrix-pipe write -> VALU read needs up to 11 wait states for this 4-pass instruction); LDS-read -> MFMA
+// operand dependencies are still tracked (s_waitcnt is inserted for asm operands), and accumulate chains on the same
+// destination are interlocked by the hardware (and separated by two other MFMAs here).
+__device__ __forceinline__ f32x4 mma16a(const bf16x8& w, const bf16x8& x, f32x4 c) {
+  // s_nop 1: where hipcc had to move a fragment into the AGPR (or just zeroed the accumulator) with VALU instructions,
+  // the 2 wait states a VALU write needs before an MFMA reads it; hipcc cannot know that this asm is an MFMA
+  asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "a"(w), "v"(x));
+  return c;
+}
+// tied to the accumulators: every MFMA that produces them is ordered before it and every consumer after it (a bare
+// asm volatile would not order the non-volatile MFMA asms)
+#define PG_MFMA_DRAIN(a0, a1, a2, a3) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3))
 __device__ __forceinline__ bf16x4 to_bf16x4(const float (&v)[4]) {
   bf16x4 o;
   o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
@@ -275,9 +292,9 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int ks = gk * 4 + i;
-            acc[0] = mma16(wh[0][ks], f[gk][i], acc[0]);
-            acc[1] = mma16(wh[1][ks], f[gk][i], acc[1]);
-            acc[2] = mma16(wh[2][ks], f[gk][i], acc[2]);
+            acc[0] = mma16a(wh[0][ks], f[gk][i], acc[0]);
+            acc[1] = mma16a(wh[1][ks], f[gk][i], acc[1]);
+            acc[2] = mma16a(wh[2][ks], f[gk][i], acc[2]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -305,13 +322,14 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int ks = gk * 4 + i;
-            acc[0] = mma16(wi[0][ks], fx[gk][i], acc[0]);
+            acc[0] = mma16a(wi[0][ks], fx[gk][i], acc[0]);
             acc[1] = mma16(wi[1][ks], fx[gk][i], acc[1]);
             acc[3] = mma16(fw[gk][i], fx[gk][i], acc[3]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      PG_MFMA_DRAIN(acc[0], acc[1], acc[2], acc[3]);
       // ---- epilogue on 4 units of sequence b; inputs from the tile's epilogue block (chunk q of row r sits at q ^ r)
       const char* E = tb + ACTB + lr * 256 + (((wave * 4 + lq) ^ lr) << 4);
       const f32x4 hp4 = *reinterpret_cast<const f32x4*>(E);

@@ -46,7 +46,7 @@ def test_persistent_matches_per_step(n, p_drop):
         for i, p in enumerate(model._engine.params()):   # flat order = optimiser order
             k = p.numel()
             a, b = got[2][off:off + k], ref[2][off:off + k]
-            assert rel_err(a, b) <= 2e-2, (mask, i, tuple(p.shape), rel_err(a, b))
+            assert rel_err(a, b) <= 5e-3, (mask, i, tuple(p.shape), rel_err(a, b))   # measured 8e-4; a mis-ordered MFMA shows as 3e-2 .. 2e-1
             off += k
     # determinism of the persistent path: run to run identical apart from the fp32 atomics of the weight-gradient GEMMs
     a = _run(model, opt, batch, eps, p_drop, 0)
