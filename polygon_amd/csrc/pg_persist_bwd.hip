@@ -34,6 +34,13 @@ constexpr int PART_BYTES = 16 * 1024;   // 16 rows x 512 bf16
 __device__ __forceinline__ f32x4 mma16(const bf16x8& w, const bf16x8& x, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0);
 }
+// the stationary weight fragment straight from an AGPR, hazard nops inside (see pg_persist_dec.hip for the why)
+__device__ __forceinline__ f32x4 mma16a(const bf16x8& w, const bf16x8& x, f32x4 c) {
+  asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "a"(w), "v"(x));
+  return c;
+}
+// matrix-pipe write -> VALU read wait states; tied to the accumulators so that every MFMA asm is ordered before it
+#define PG_MFMA_DRAIN(a0, a1, a2, a3) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3))
 __device__ __forceinline__ bf16x4 to_bf16x4(const float (&v)[4]) {
   bf16x4 o;
   o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
@@ -256,7 +263,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ah[i & 1] = mma16(wh[p * 16 + gk * 4 + i], f[gk][i], ah[i & 1]);
+            for (int i = 0; i < 4; ++i) ah[i & 1] = mma16a(wh[p * 16 + gk * 4 + i], f[gk][i], ah[i & 1]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -283,7 +290,10 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
               }
               __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-              for (int i = 0; i < 4; ++i) au[i & 1] = mma16(wu[p * 16 + gk * 4 + i], f[gk][i], au[i & 1]);
+              for (int i = 0; i < 4; ++i) {
+                if (p == 0) au[i & 1] = mma16a(wu[p * 16 + gk * 4 + i], f[gk][i], au[i & 1]);
+                else au[i & 1] = mma16(wu[p * 16 + gk * 4 + i], f[gk][i], au[i & 1]);
+              }
               __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -326,6 +336,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
           }
         }
       }
+      PG_MFMA_DRAIN(ah[0], ah[1], au[0], au[1]);
       if (j == 0) PG_STAMP(4);
       // ---- epilogue on 4 units of sequence b
       float dh[4];
