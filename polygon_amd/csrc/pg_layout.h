@@ -122,7 +122,7 @@ struct TrainWs {
   // int32 arrays
   size_t enc_tok, dec_tok, dec_tgt, dec_t, dec_b, dec_off;
   size_t scalars;
-  size_t sync;   // counters of the group-persistent decoder kernels (pg_persist.h), 4160 bytes
+  size_t sync;   // counters of the group-persistent decoder kernels (pg_persist.h), 8256 bytes
   // encoder
   size_t e_carry, e_hop[2], e_sv[5], e_hfin_op, e_mulv, e_eps, e_zop;
   // decoder forward
@@ -145,7 +145,7 @@ static inline TrainWs train_ws_layout(const pg_dims* d, int dtype, long B, long 
   w.enc_tok = take(Ne * 4); w.dec_tok = take(Nd * 4); w.dec_tgt = take(Nd * 4); w.dec_t = take(Nd * 4);
   w.dec_b = take(Nd * 4); w.dec_off = take((PG_MAX_T + 2) * 4);
   w.scalars = take(SC_N * 4);
-  w.sync = take(1040 * 4);
+  w.sync = take(2064 * 4);   // PG_PERSIST_SYNC_WORDS (pg_persist.h)
   w.e_carry = take(B * Hq * 4); w.e_hop[0] = take(B * Hq * es); w.e_hop[1] = take(B * Hq * es);
   for (int i = 0; i < 5; ++i) w.e_sv[i] = take(Ne * Hq * es);
   w.e_hfin_op = take(B * Hq * es); w.e_mulv = take(B * 2 * Dz * 4); w.e_eps = take(B * Dz * 4); w.e_zop = take(B * Dz * es);

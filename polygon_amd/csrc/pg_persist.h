@@ -70,7 +70,30 @@ struct DecFwdPersist {
   unsigned long long* stamps = nullptr;       // development aid: wall-clock stamps of one workgroup (pg_persist_stamps)
   int dbg = 0;                                // development aid (PG_PERSIST_DBG): 1 no DMA, 2 no MFMA, 4 no epilogue stores, 8 no epilogue loads
 };
-constexpr int PG_PERSIST_SYNC_WORDS = 1040;   // counters [8 groups][PG_MAX_LAYERS] at a 16-word stride, then the give-up word
+constexpr int PG_PERSIST_MAX_GROUPS = 16;
+constexpr int PG_PERSIST_SYNC_WORDS = PG_PERSIST_MAX_GROUPS * PG_MAX_LAYERS * 16 + 16;   // counters [group][layer] at a 16-word stride, then the give-up word
+
+// Number of groups for a batch: 8 (one per XCD, 192 workgroups) or - with 3 layers, when it saves a 16-row tile per step
+// - 10: groups 8 and 9 take the 8 spare CUs of XCDs 0-2 and 3-5, one LAYER per XCD, so that the 8 slices of a layer still
+// share an L2 (256 workgroups, the 16 on XCDs 6-7 idle).  Placement is a speed matter only.
+static inline int persist_groups(int L, int B) {
+  auto tiles = [&](int ng) { return ((B + ng - 1) / ng + 15) / 16; };
+  return (L == 3 && tiles(10) < tiles(8)) ? 10 : 8;
+}
+// workgroup -> (group, layer-order index k/NCU, slice); false: idle workgroup
+__device__ __forceinline__ bool persist_map(int bid, int NG, int NCU, int& g, int& li, int& c) {
+  if (NG == 8) {
+    g = bid % 8;
+    const int k = bid / 8;
+    li = k / NCU; c = k % NCU;
+    return true;
+  }
+  const int xcd = bid % 8, slot = bid / 8;           // NG == 10: 32 slots per XCD, NCU == 8, 3 layers
+  if (slot < 3 * NCU) { g = xcd; li = slot / NCU; c = slot % NCU; return true; }
+  if (xcd >= 6) return false;
+  g = 8 + xcd / 3; li = xcd % 3; c = slot - 3 * NCU;
+  return true;
+}
 
 // Decoder stack, backward (BPTT): the same grouping, workgroup (layer l, slice c) keeps the rows of W_hh_l^T and
 // W_ih_{l+1}^T that produce dh of its 64 units.  It consumes dGH_{l,t+1} (own layer) and dGI_{l+1,t} (layer above) as

@@ -25,7 +25,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 namespace {
 
 constexpr int SYNC_STRIDE = 16;
-constexpr int SYNC_ERR = PG_MAX_LAYERS * 8 * SYNC_STRIDE;
+constexpr int SYNC_ERR = PG_MAX_LAYERS * PG_PERSIST_MAX_GROUPS * SYNC_STRIDE;
 static_assert(SYNC_ERR + 1 <= PG_PERSIST_SYNC_WORDS, "sync block too small");
 constexpr unsigned SPIN_LIMIT = 1u << 21;
 constexpr int AUX_SC1 = 16;
@@ -394,9 +394,10 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
 template <int H, int AUXL>
 __global__ __launch_bounds__(256) void dec_bwd_persist_kernel(DecBwdPersist a, Sched sd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int g = blockIdx.x % a.NG, k = blockIdx.x / a.NG;   // blockIdx % 8 labels the XCD: a group's workgroups share one
   constexpr int NCU = H / 64;
-  const int l = a.L - 1 - k / NCU, c = k % NCU;             // top layer first: it is the head of the dependency chain
+  int g, li, c;   // blockIdx % 8 labels the XCD: a group's workgroups (or at least a layer's) share one
+  if (!persist_map(blockIdx.x, a.NG, NCU, g, li, c)) return;
+  const int l = a.L - 1 - li;                               // top layer first: it is the head of the dependency chain
   if (l == a.L - 1) dec_bwd_body<H, true, AUXL>(a, sd, g, l, c, smem);
   else dec_bwd_body<H, false, AUXL>(a, sd, g, l, c, smem);
 }
@@ -426,7 +427,7 @@ int launch_dec_bwd_persist(DecBwdPersist& a, const Sched& sd, int H, float* dh0_
   using GL = BwdGeo<512, false>;
   using GT = BwdGeo<512, true>;
   constexpr int SMEM = GL::SMEM > GT::SMEM ? GL::SMEM : GT::SMEM;
-  a.NG = 8;
+  a.NG = persist_groups(a.L, a.B);
   PG_TRY(persist_fail_words(&a.fail));
   a.stamps = persist_stamps_for(1);
   a.dbg = getenv("PG_PERSIST_DBG") ? atoi(getenv("PG_PERSIST_DBG")) : 0;
@@ -439,7 +440,7 @@ int launch_dec_bwd_persist(DecBwdPersist& a, const Sched& sd, int H, float* dh0_
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_done = true;
   }
-  const int grid = a.NG * a.L * GL::NCU;   // co-residency: one workgroup per CU (checked against the CU count by the forward launcher's rule)
+  const int grid = a.NG == 8 ? 8 * a.L * GL::NCU : 256;   // co-residency: one workgroup per CU (checked against the CU count by the forward launcher's rule)
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;

@@ -24,7 +24,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 namespace {
 
 constexpr int SYNC_STRIDE = 16;                                   // words between counters (one 64-byte line each)
-constexpr int SYNC_ERR = PG_MAX_LAYERS * 8 * SYNC_STRIDE;         // give-up word, after the [8][PG_MAX_LAYERS] counters
+constexpr int SYNC_ERR = PG_MAX_LAYERS * PG_PERSIST_MAX_GROUPS * SYNC_STRIDE;         // give-up word, after the [8][PG_MAX_LAYERS] counters
 static_assert(SYNC_ERR + 1 <= PG_PERSIST_SYNC_WORDS, "sync block too small");
 constexpr unsigned SPIN_LIMIT = 1u << 21;                         // ~2-4 s of polling before a workgroup gives up
 constexpr int AUX_SC1 = 16;
@@ -404,8 +404,8 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
 template <int H, int AUXL>
 __global__ __launch_bounds__(256) void dec_fwd_persist_kernel(DecFwdPersist a, Sched sd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int g = blockIdx.x % a.NG, k = blockIdx.x / a.NG;   // blockIdx % 8 labels the XCD: a group's workgroups share one
-  const int l = k / DecGeo<H>::NCU, c = k % DecGeo<H>::NCU;
+  int g, l, c;   // blockIdx % 8 labels the XCD: a group's workgroups (or at least a layer's) share one
+  if (!persist_map(blockIdx.x, a.NG, DecGeo<H>::NCU, g, l, c)) return;
   if (l == 0) dec_fwd_body<H, true, AUXL>(a, sd, g, l, c, smem);
   else dec_fwd_body<H, false, AUXL>(a, sd, g, l, c, smem);
 }
@@ -449,7 +449,7 @@ int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t
   PG_REQUIRE(dec_persist_supported(H, a.L, a.B), "dec_fwd_persist: shape H=%d L=%d not covered", H, a.L);
   PG_REQUIRE(a.sync && a.table && a.tok && a.zproj && a.h0_op && a.h0_32, "dec_fwd_persist: NULL buffer");
   using G = DecGeo<512>;
-  a.NG = 8;   // one group per XCD
+  a.NG = persist_groups(a.L, a.B);
   PG_TRY(persist_fail_words(&a.fail));
   a.stamps = g_stamps_which == 0 ? g_stamps : nullptr;
   a.dbg = getenv("PG_PERSIST_DBG") ? atoi(getenv("PG_PERSIST_DBG")) : 0;
@@ -465,7 +465,7 @@ int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t
   // Every workgroup waits for its peers, so the whole grid must be co-resident: one workgroup per CU (512 registers per
   // lane, 130 KB LDS) on a device with at least `grid` CUs.  Checked here; a plain launch has the same residency as a
   // cooperative one and works when several processes use the GPU (their kernels drain independently, waits are bounded).
-  const int grid = a.NG * a.L * G::NCU;
+  const int grid = a.NG == 8 ? 8 * a.L * G::NCU : 256;
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;

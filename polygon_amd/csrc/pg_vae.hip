@@ -393,7 +393,7 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
   bool persist = false;
   if constexpr (std::is_same<T, bf16_t>::value) {
     if (use_persistent_dec(Hd, L, B)) {   // ONE launch: weights stationary per workgroup, layers pipelined through counters
-      static_assert(PG_PERSIST_SYNC_WORDS == 1040, "TrainWs::sync is sized for 1040 words");
+      static_assert(PG_PERSIST_SYNC_WORDS == 2064, "TrainWs::sync is sized for 2064 words");
       DecFwdPersist pa;
       pa.L = L; pa.B = B;
       for (int l = 0; l < L; ++l) {
