@@ -174,7 +174,7 @@ static inline TrainWs train_ws_layout(const pg_dims* d, int dtype, long B, long 
 }
 
 struct SampleWs {
-  size_t zop, zproj, h0_32, h0_op, carry[PG_MAX_LAYERS], hop[PG_MAX_LAYERS][2], tok, eos;
+  size_t zop, zproj, h0_32, h0_op, carry[PG_MAX_LAYERS], hop[PG_MAX_LAYERS][2], tok, eos, sync;
   size_t total;
 };
 static inline SampleWs sample_ws_layout(const pg_dims* d, int dtype, long n) {
@@ -189,6 +189,7 @@ static inline SampleWs sample_ws_layout(const pg_dims* d, int dtype, long n) {
     w.hop[l][0] = take(n * Hd * es); w.hop[l][1] = take(n * Hd * es);
   }
   w.tok = take(n * 4); w.eos = take(n * 4);
+  w.sync = take(4112 * 4);   // PG_SAMPLE_SYNC_WORDS (pg_persist.h)
   w.total = p;
   return w;
 }

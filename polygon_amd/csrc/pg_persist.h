@@ -117,6 +117,41 @@ struct DecBwdPersist {
   int dbg = 0;                                // development aid (PG_PERSIST_DBG): 1 no DMA, 2 no MFMA, 4 no epilogue I/O
 };
 
+// Autoregressive sampler, whole decode loop in one launch (pg_persist_sample.hip): 8 groups x (3 layers x 8 slices + 8
+// head workgroups); a group's rows travel in S sub-batches of TS 16-row tiles round the stages l0 -> l1 -> l2 -> head.
+constexpr int PG_SAMPLE_MAX_SUB = 8;          // sub-batches per group
+constexpr int PG_SAMPLE_MAX_TS = 16;          // 16-row tiles per sub-batch (the token block of layer 0 in LDS)
+constexpr int PG_SAMPLE_SYNC_WORDS = 8 * 4 * PG_SAMPLE_MAX_SUB * 16 + 16;   // counters [group][stage][sub-batch] at a 16-word stride, then the give-up word
+struct DecSamplePersist {
+  int L = 0, n = 0, T = 0;                    // rows, decode steps (max_len - 1)
+  int ntile = 0, S = 0, TS = 0;               // set by the launcher
+  const bf16_t* Whh[PG_MAX_LAYERS] = {};      // [3H, H]
+  const bf16_t* Wih[PG_MAX_LAYERS] = {};      // [3H, H] for l >= 1
+  const float* bhn[PG_MAX_LAYERS] = {};       // [H]
+  const float* bias_gi[PG_MAX_LAYERS] = {};   // [3H] for l >= 1
+  const float* table = nullptr;               // layer 0: [V, 3H]
+  const float* zproj = nullptr;               // [n, 3H]
+  bf16_t* hop[PG_MAX_LAYERS][2] = {};         // [n, H] layer outputs, ping-pong by step parity; [l][0] = h0 on entry
+  float* carry[PG_MAX_LAYERS] = {};           // [n, H] fp32 state; = h0 on entry
+  int* tok = nullptr;                         // [n] token fed to the next step; = bos on entry
+  int* eos = nullptr;                         // [n] row has ended; = 0 on entry
+  const bf16_t* fcw = nullptr;                // [64, H] vocabulary projection (rows >= V zero)
+  const float* fcb = nullptr;                 // [64]
+  int V = 0, multinomial = 1, eos_id = 0, max_len = 0;
+  float inv_temp = 1.0f;
+  const float* uniforms = nullptr;            // [max_len - 1, n] pre-drawn, or null: Philox(seed, row_offset + row, step)
+  uint64_t seed = 0;
+  long row_offset = 0;
+  uint8_t* tokens = nullptr;                  // [n, max_len], initialised (bos, pad...) on entry
+  int* end_pads = nullptr;                    // [n], = max_len on entry
+  unsigned* sync = nullptr;                   // PG_SAMPLE_SYNC_WORDS words, zeroed by the launcher
+  unsigned* fail = nullptr;                   // set by the launcher
+};
+bool dec_sample_persist_supported(int Hd, int L, int V, long n);
+int launch_dec_sample_persist(DecSamplePersist& a, hipStream_t stream);
+// PG_NO_PERSIST / pg_persist_disable mask (pg_vae.hip): bit 0 encoder, 1 decoder forward, 2 decoder BPTT, 3 sampler
+int persist_off_mask();
+
 bool dec_persist_supported(int H, int L, int B);
 int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t stream);
 // runs the whole decoder BPTT recurrence, then dh0_32 / dh0_op [B, H] = sum over layers of the h0 gradients

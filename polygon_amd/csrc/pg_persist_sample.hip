@@ -1,0 +1,463 @@
+// Group-persistent autoregressive sampler (VAE.sample, vae_model.py:300-358): ONE launch decodes every step of every row.
+//
+// The per-step path (pg_sample.hip) launches 3 GRU cells + 1 head kernel per token and re-reads the decoder's 9.4 MB of
+// weights from L2 in every launch.  Here the weights are stationary, exactly as in the training forward kernel
+// (pg_persist_dec.hip): group g (one XCD) owns rows g, g+8, g+16, ...; workgroup (g, layer l, slice c) keeps the W_hh /
+// W_ih rows of 64 hidden units in registers + LDS and streams 16-row tiles of [h_{l,t-1} | h_{l-1,t}] through LDS-DMA.
+// What is new is the feedback: layer 0 of step t+1 needs the token drawn from the top layer's output of step t.  A fourth
+// stage per group, the HEAD workgroups (8 per group, a tile each in turn), closes the loop: vocabulary projection on MFMA
+// (W_fc stationary in registers), softmax and inverse-CDF draw (the arithmetic of sample_head_kernel, operation for
+// operation), eos bookkeeping, and the token is published for layer 0.
+// Rows are independent, so a group splits its rows into S SUB-BATCHES that travel round the 4-stage ring
+// l0 -> l1 -> l2 -> head -> l0 one behind the other: with S >= 4 every stage has a sub-batch to work on while the others
+// are elsewhere.  Hand-off: one arrival counter per (group, stage, sub-batch); stage k starts (t, s) when stage k-1 has
+// completed (t, s) and all slices of stage k have completed (t-1, s); layer 0 waits for the head's (t-1, s).  Published
+// rows are write-through stores read with sc1 loads; every wait is bounded (pg_persist_dec.hip, protocol).
+// h_{l,t} ping-pongs between two [n, H] buffers per layer: h_{l,t+1} may overwrite h_{l,t-1} because the token feedback
+// orders (l, t+1, s) behind the head's (t, s), hence behind every reader of h_{l,t-1}.
+#include <hip/hip_runtime.h>
+#include "pg_mma.h"
+#include "pg_persist.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+namespace {
+
+constexpr int H = 512, KS = H / 32, NCU = H / 64, NG = 8, NH = 8, NSTAGE = 4;
+constexpr int SYNC_STRIDE = 16;
+constexpr int SYNC_ERR = NG * NSTAGE * PG_SAMPLE_MAX_SUB * SYNC_STRIDE;
+static_assert(SYNC_ERR + 1 <= PG_SAMPLE_SYNC_WORDS, "sync block too small");
+constexpr unsigned SPIN_LIMIT = 1u << 21;
+constexpr int AUX_SC1 = 16;
+constexpr int ROWW = H * 2 + 16;
+constexpr int WIN_BYTES = 64 * ROWW;
+constexpr int ACT_BYTES = 16 * 2 * H * 2;
+constexpr int CARRY_BYTES = 16 * 64 * 4;
+constexpr int GATE_BYTES = 3 * CARRY_BYTES;
+constexpr int TILE_BYTES = ACT_BYTES + CARRY_BYTES;
+constexpr int TILE0_BYTES = ACT_BYTES / 2 + CARRY_BYTES + 2 * GATE_BYTES;
+constexpr int TOK_BYTES = 16 * PG_SAMPLE_MAX_TS * 4;
+constexpr int SMEM = WIN_BYTES + 2 * TILE_BYTES + 16;
+static_assert(2 * TILE0_BYTES + TOK_BYTES + 16 <= SMEM, "layer-0 layout must fit the common allocation");
+static_assert(16 * 1024 + 16 * 65 * 4 + 16 <= SMEM, "head layout must fit the common allocation");
+
+__device__ __forceinline__ f32x4 mma16(const bf16x8& w, const bf16x8& x, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0);
+}
+// weight operand straight from an AGPR; see pg_persist_dec.hip for the hazard rules
+__device__ __forceinline__ f32x4 mma16a(const bf16x8& w, const bf16x8& x, f32x4 c) {
+  asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "a"(w), "v"(x));
+  return c;
+}
+#define PG_MFMA_DRAIN(a0, a1, a2, a3) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3))
+__device__ __forceinline__ bf16x4 to_bf16x4(const float (&v)[4]) {
+  bf16x4 o;
+  o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+  return o;
+}
+
+__device__ __forceinline__ bool wait_ge(unsigned* p, unsigned target, unsigned* err, unsigned* sticky) {
+  for (unsigned spins = 0;; ++spins) {
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+    if ((spins & 63u) == 63u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+    if (spins > SPIN_LIMIT) {
+      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+__device__ __forceinline__ unsigned* counter(const DecSamplePersist& a, int g, int stage, int s) {
+  return a.sync + ((g * NSTAGE + stage) * PG_SAMPLE_MAX_SUB + s) * SYNC_STRIDE;
+}
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// one GRU layer of the group: the tile loop of dec_fwd_body (pg_persist_dec.hip) without the training outputs
+template <bool L0>
+__device__ __forceinline__ void layer_body(const DecSamplePersist& a, int g, int l, int c, char* smem) {
+  char* sWin = smem;
+  char* sA = smem + WIN_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int uw = c * 64 + wave * 16;
+  const int u0 = uw + lq * 4;
+  const int n = a.n;
+
+  const bf16_t* Whh = a.Whh[l];
+  const bf16_t* Wih = a.Wih[l];
+  bf16x8 wh[3][KS];
+#pragma unroll
+  for (int gt = 0; gt < 3; ++gt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      wh[gt][ks] = *reinterpret_cast<const bf16x8*>(Whh + (long)(gt * H + uw + lr) * H + (ks * 4 + lq) * 8);
+  bf16x8 wi[2][L0 ? 1 : KS];
+  if constexpr (!L0) {
+#pragma unroll
+    for (int gt = 0; gt < 2; ++gt)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        wi[gt][ks] = *reinterpret_cast<const bf16x8*>(Wih + (long)(gt * H + uw + lr) * H + (ks * 4 + lq) * 8);
+    for (int id = tid; id < 64 * (H / 8); id += 256) {
+      const int u = id / (H / 8), ch = id % (H / 8);
+      *reinterpret_cast<uint4*>(sWin + u * ROWW + ch * 16) =
+          *reinterpret_cast<const uint4*>(Wih + (long)(2 * H + c * 64 + u) * H + ch * 8);
+    }
+  }
+  float bh[4], bgi[3][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    bh[e] = a.bhn[l][u0 + e];
+#pragma unroll
+    for (int gt = 0; gt < 3; ++gt) bgi[gt][e] = L0 ? 0.0f : a.bias_gi[l][gt * H + u0 + e];
+  }
+  float* carry = a.carry[l];
+  const __amdgpu_buffer_rsrc_t r_carry = pg_make_rsrc(carry);
+  unsigned* err = a.sync + SYNC_ERR;
+  __syncthreads();
+
+  constexpr int PARTS = L0 ? 1 : 2;
+  constexpr int RP_WAVE = 16 * PARTS / 4;
+  constexpr int TILEB = L0 ? TILE0_BYTES : TILE_BYTES;
+  constexpr int ACTB = ACT_BYTES / (L0 ? 2 : 1);
+  char* sT = L0 ? smem : sA;
+  int* sTok = reinterpret_cast<int*>(smem + 2 * TILE0_BYTES);      // layer 0 only
+  volatile unsigned* sFlagT = reinterpret_cast<volatile unsigned*>(smem + SMEM - 16);
+  constexpr int NS = 2;                                            // stores per wave and tile: state, published h
+  constexpr int ND = RP_WAVE + 1 + (L0 ? 6 : 0);                   // DMA instructions per wave and tile
+  static_assert(ND == 9 || ND == 11, "unexpected tile shape");
+  const float* carry_src = carry + c * 64;
+
+  for (int t = 0; t < a.T; ++t) {
+    const int p = t & 1;
+    const bf16_t* hprev_base = a.hop[l][p];
+    const bf16_t* x_base = L0 ? hprev_base : a.hop[l - 1][p ^ 1];
+    const __amdgpu_buffer_rsrc_t r_h = pg_make_rsrc(a.hop[l][p ^ 1]);
+    for (int s = 0; s < a.S; ++s) {
+      const int j0 = s * a.TS;
+      const int j1 = j0 + a.TS < a.ntile ? j0 + a.TS : a.ntile;
+      // ---- wait for (l, t-1, s) of every slice and for the stage below: (l-1, t, s), or the head's (t-1, s)
+      if (tid == 0) {
+        bool ok = wait_ge(counter(a, g, l, s), (unsigned)(NCU * t), err, a.fail);
+        if (ok) {
+          if constexpr (L0) ok = wait_ge(counter(a, g, NSTAGE - 1, s), (unsigned)(NH * t), err, a.fail);
+          else ok = wait_ge(counter(a, g, l - 1, s), (unsigned)(NCU * (t + 1)), err, a.fail);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *sFlagT = ok ? 1u : 0u;
+      }
+      __syncthreads();
+      if (*sFlagT == 0u) return;   // block-uniform: somebody gave up
+      if constexpr (L0) {          // the sub-batch's tokens (drawn by the head workgroups in this launch: coherent loads)
+        for (int i = tid; i < 16 * (j1 - j0); i += 256) {
+          const int b = g + NG * (16 * j0 + i);
+          sTok[i] = b < n ? __hip_atomic_load(a.tok + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        }
+        __syncthreads();
+      }
+
+      auto stage = [&](int j, int buf) __attribute__((always_inline)) {
+        char* tb = sT + buf * TILEB;
+#pragma unroll
+        for (int i = 0; i < RP_WAVE; ++i) {
+          const int rp = wave * RP_WAVE + i;
+          const int row = rp / PARTS, part = rp % PARTS;
+          const int b = g + NG * (16 * j + row);
+          const int bs = b < n ? b : g;
+          const bf16_t* src = (part == 0 ? hprev_base : x_base) + (long)bs * H + ((lane ^ (row & 15)) * 8);
+          char* dst = tb + row * (PARTS * 1024) + part * 1024;
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, AUX_SC1);
+        }
+        {
+          const int row = wave * 4 + (lane >> 4), ch = (lane & 15) ^ row;
+          const int i = 16 * j + row;
+          const int b = g + NG * i;
+          const int bs = b < n ? b : g;
+          char* eb = tb + ACTB + wave * 1024;
+          __builtin_amdgcn_global_load_lds((gptr_t)(carry_src + (long)bs * H + ch * 4), (lptr_t)eb, 16, 0, 0);
+          if constexpr (L0) {
+            const float* tp = a.table + (long)sTok[i - 16 * j0] * 3 * H + c * 64 + ch * 4;
+            const float* zp = a.zproj + (long)bs * 3 * H + c * 64 + ch * 4;
+#pragma unroll
+            for (int gt = 0; gt < 3; ++gt) {
+              __builtin_amdgcn_global_load_lds((gptr_t)(tp + gt * H), (lptr_t)(eb + CARRY_BYTES + gt * CARRY_BYTES), 16, 0, 0);
+              __builtin_amdgcn_global_load_lds((gptr_t)(zp + gt * H), (lptr_t)(eb + CARRY_BYTES + GATE_BYTES + gt * CARRY_BYTES), 16, 0, 0);
+            }
+          }
+        }
+      };
+      stage(j0, 0);
+      if (j1 - j0 > 1) {           // block-uniform
+        stage(j0 + 1, 1);
+        if constexpr (ND == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      for (int j = j0; j < j1; ++j) {
+        const int buf = (j - j0) & 1;
+        const int b = g + NG * (16 * j + lr);
+        const bool live = b < n;
+        const char* tb = sT + buf * TILEB;
+        f32x4 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* A = tb + lr * (PARTS * 1024) + ((lq ^ lr) & 3) * 16;
+        const int hi = lr >> 2;
+        {
+          bf16x8 f[KS / 4][4];
+#pragma unroll
+          for (int gk = 0; gk < 2; ++gk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) f[gk][i] = *reinterpret_cast<const bf16x8*>(A + (((gk * 4 + i) ^ hi) << 6));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int gk = 0; gk < KS / 4; ++gk) {
+            if (gk + 2 < KS / 4) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) f[gk + 2][i] = *reinterpret_cast<const bf16x8*>(A + ((((gk + 2) * 4 + i) ^ hi) << 6));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int ks = gk * 4 + i;
+              acc[0] = mma16a(wh[0][ks], f[gk][i], acc[0]);
+              acc[1] = mma16a(wh[1][ks], f[gk][i], acc[1]);
+              acc[2] = mma16a(wh[2][ks], f[gk][i], acc[2]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if constexpr (!L0) {
+          const char* Wn = sWin + (wave * 16 + lr) * ROWW + lq * 16;
+          bf16x8 fx[KS / 4][4], fw[KS / 4][4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            fx[0][i] = *reinterpret_cast<const bf16x8*>(A + 1024 + ((i ^ hi) << 6));
+            fw[0][i] = *reinterpret_cast<const bf16x8*>(Wn + i * 64);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int gk = 0; gk < KS / 4; ++gk) {
+            if (gk + 1 < KS / 4) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const int ks = (gk + 1) * 4 + i;
+                fx[gk + 1][i] = *reinterpret_cast<const bf16x8*>(A + 1024 + ((ks ^ hi) << 6));
+                fw[gk + 1][i] = *reinterpret_cast<const bf16x8*>(Wn + ks * 64);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int ks = gk * 4 + i;
+              acc[0] = mma16a(wi[0][ks], fx[gk][i], acc[0]);
+              acc[1] = mma16(wi[1][ks], fx[gk][i], acc[1]);
+              acc[3] = mma16(fw[gk][i], fx[gk][i], acc[3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        PG_MFMA_DRAIN(acc[0], acc[1], acc[2], acc[3]);
+        const char* E = tb + ACTB + lr * 256 + (((wave * 4 + lq) ^ lr) << 4);
+        const f32x4 hp4 = *reinterpret_cast<const f32x4*>(E);
+        f32x4 g3[3];
+        if constexpr (L0) {
+#pragma unroll
+          for (int gt = 0; gt < 3; ++gt)
+            g3[gt] = *reinterpret_cast<const f32x4*>(E + CARRY_BYTES + gt * CARRY_BYTES) +
+                     *reinterpret_cast<const f32x4*>(E + CARRY_BYTES + GATE_BYTES + gt * CARRY_BYTES);
+        } else {
+#pragma unroll
+          for (int gt = 0; gt < 3; ++gt) g3[gt] = f32x4{bgi[gt][0], bgi[gt][1], bgi[gt][2], bgi[gt][3]};
+        }
+        float h[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float r = sigmoidf_(g3[0][e] + acc[0][e]);
+          const float z = sigmoidf_(g3[1][e] + acc[1][e]);
+          const float hn = acc[2][e] + bh[e];
+          const float nn = tanhf_(g3[2][e] + acc[3][e] + r * hn);
+          h[e] = (1.0f - z) * nn + z * hp4[e];
+        }
+        // tile j+1 has landed: everything older than the previous tile's NS stores (see pg_persist_dec.hip)
+        if (j > j0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        static_assert(NS == 2, "the wait above counts two stores per tile");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j + 2 < j1) stage(j + 2, buf);           // block-uniform
+        asm volatile("" ::: "memory");
+        {
+          const unsigned oob = 0x80000000u;          // beyond the descriptor's records: the store is dropped
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{h[0], h[1], h[2], h[3]}), r_carry,
+                                                 (int)(live ? (unsigned)(((long)b * H + u0) * 4) : oob), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, to_bf16x4(h)), r_h,
+                                                (int)(live ? (unsigned)(((long)b * H + u0) * 2) : oob), 0, AUX_SC1);
+        }
+      }
+      // ---- publish (t, s) of this unit slice
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(counter(a, g, l, s), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// head workgroup hc of group g: tiles j0 + hc, j0 + hc + NH, ... of every sub-batch
+__device__ __forceinline__ void head_body(const DecSamplePersist& a, int g, int hc, char* smem) {
+  char* sA = smem;                                                 // [16 rows][1 KB], chunk q of row r at q ^ r
+  float* sl = reinterpret_cast<float*>(smem + 16 * 1024);          // [16][65] logits
+  volatile unsigned* sFlagT = reinterpret_cast<volatile unsigned*>(smem + SMEM - 16);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int n = a.n, V = a.V, top = a.L - 1;
+  bf16x8 wf[KS];                                                   // W_fc rows 16*wave + lr (padded to 64 rows)
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+    wf[ks] = *reinterpret_cast<const bf16x8*>(a.fcw + (long)(wave * 16 + lr) * H + (ks * 4 + lq) * 8);
+  unsigned* err = a.sync + SYNC_ERR;
+
+  for (int t = 0; t < a.T; ++t) {
+    const int step = t + 1;                                        // column of the token matrix this step fills
+    const bf16_t* htop = a.hop[top][(t & 1) ^ 1];
+    for (int s = 0; s < a.S; ++s) {
+      const int j0 = s * a.TS;
+      const int j1 = j0 + a.TS < a.ntile ? j0 + a.TS : a.ntile;
+      if (tid == 0) {
+        const bool ok = wait_ge(counter(a, g, top, s), (unsigned)(NCU * (t + 1)), err, a.fail);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *sFlagT = ok ? 1u : 0u;
+      }
+      __syncthreads();
+      if (*sFlagT == 0u) return;
+      for (int j = j0 + hc; j < j1; j += NH) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = wave * 4 + i;
+          const int b = g + NG * (16 * j + row);
+          const int bs = b < n ? b : g;
+          __builtin_amdgcn_global_load_lds((gptr_t)(htop + (long)bs * H + ((lane ^ row) * 8)), (lptr_t)(sA + row * 1024), 16, 0,
+                                           AUX_SC1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* A = sA + lr * 1024 + ((lq ^ lr) & 3) * 16;
+        const int hi = lr >> 2;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = mma16(wf[ks], *reinterpret_cast<const bf16x8*>(A + ((ks ^ hi) << 6)), acc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sl[lr * 65 + wave * 16 + lq * 4 + e] = acc[e];
+        __syncthreads();
+        const int b = g + NG * (16 * j + tid);
+        if (tid < 16 && b < n) {                                   // one lane per row: sample_head_kernel's arithmetic
+          float* y = sl + tid * 65;
+          float mx = -INFINITY;
+          int amax = 0;
+          for (int v = 0; v < V; ++v) {
+            const float x = (y[v] + a.fcb[v]) * a.inv_temp;
+            y[v] = x;
+            if (x > mx) { mx = x; amax = v; }
+          }
+          int w = amax;
+          if (a.multinomial) {
+            float sum = 0.0f;
+            for (int v = 0; v < V; ++v) {
+              const float e = __expf(y[v] - mx);
+              y[v] = e;
+              sum += e;
+            }
+            float u;
+            if (a.uniforms) u = a.uniforms[(long)(step - 1) * n + b];
+            else {
+              const unsigned long long gr = (unsigned long long)(a.row_offset + b);
+              Philox4 r = philox4x32_10((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)step, 0x5A17u, (uint32_t)a.seed,
+                                        (uint32_t)(a.seed >> 32));
+              u = pg_u01(r.x);
+            }
+            float cdf = 0.0f;
+            w = V - 1;
+            for (int v = 0; v < V; ++v) {
+              cdf += y[v] / sum;
+              if (cdf > u) { w = v; break; }
+            }
+          }
+          __hip_atomic_store(a.tok + b, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // published for layer 0
+          if (!a.eos[b]) {                                         // eos[b] is only ever touched by this workgroup
+            a.tokens[(long)b * a.max_len + step] = (uint8_t)w;
+            if (w == a.eos_id) { a.end_pads[b] = step + 1; a.eos[b] = 1; }
+          }
+        }
+        __syncthreads();                                           // sA / sl are reused by the next tile
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(counter(a, g, NSTAGE - 1, s), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void dec_sample_persist_kernel(DecSamplePersist a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int g = blockIdx.x % NG;              // blockIdx % 8 labels the XCD: a group lives on one
+  const int k = blockIdx.x / NG;
+  if (k < NCU) layer_body<true>(a, g, 0, k, smem);
+  else if (k < 3 * NCU) layer_body<false>(a, g, k / NCU, k % NCU, smem);
+  else head_body(a, g, k - 3 * NCU, smem);
+}
+
+}  // namespace
+
+bool dec_sample_persist_supported(int Hd, int L, int V, long n) {
+  return Hd == H && L == 3 && V <= 64 && n >= 1 && n <= (long)NG * 16 * PG_SAMPLE_MAX_SUB * PG_SAMPLE_MAX_TS;
+}
+
+int launch_dec_sample_persist(DecSamplePersist& a, hipStream_t stream) {
+  PG_REQUIRE(dec_sample_persist_supported(H, a.L, a.V, a.n), "dec_sample_persist: shape L=%d V=%d n=%d not covered", a.L, a.V, a.n);
+  PG_REQUIRE(a.sync && a.table && a.tok && a.eos && a.zproj && a.fcw && a.fcb && a.tokens && a.end_pads, "dec_sample_persist: NULL buffer");
+  PG_REQUIRE(a.T >= 1 && a.max_len == a.T + 1, "dec_sample_persist: bad step count");
+  a.ntile = (int)((((long)a.n + NG - 1) / NG + 15) / 16);
+  // sub-batches: enough of them to keep the 4 stages of a group busy, as large as the row count allows
+  int TS = (a.ntile + PG_SAMPLE_MAX_SUB - 1) / PG_SAMPLE_MAX_SUB;
+  const int want = getenv("PG_SAMPLE_TS") ? atoi(getenv("PG_SAMPLE_TS")) : 12;
+  if (TS < want) TS = want;
+  if (TS > PG_SAMPLE_MAX_TS) TS = PG_SAMPLE_MAX_TS;
+  if (TS > a.ntile) TS = a.ntile;
+  a.TS = TS;
+  a.S = (a.ntile + TS - 1) / TS;
+  PG_REQUIRE(a.S >= 1 && a.S <= PG_SAMPLE_MAX_SUB, "dec_sample_persist: %d sub-batches", a.S);
+  PG_TRY(persist_fail_words(&a.fail));
+  PG_CHECK_HIP(hipMemsetAsync(a.sync, 0, PG_SAMPLE_SYNC_WORDS * sizeof(unsigned), stream));
+  static bool attr_done = false;
+  if (!attr_done) {
+    PG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_sample_persist_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_done = true;
+  }
+  // every workgroup waits for its peers: the grid must be co-resident, one workgroup per CU (pg_persist_dec.hip)
+  const int grid = NG * (3 * NCU + NH);
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    PG_CHECK_HIP(hipGetDevice(&dev));
+    PG_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  PG_REQUIRE(grid <= n_cu, "dec_sample_persist: %d workgroups cannot be co-resident on %d CUs", grid, n_cu);
+  hipLaunchKernelGGL(dec_sample_persist_kernel, dim3(grid), dim3(256), (size_t)SMEM, stream, a);
+  PG_CHECK_LAUNCH();
+  PG_TRY(persist_fail_mirror(stream));
+  return PG_OK;
+}

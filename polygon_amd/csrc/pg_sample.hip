@@ -7,12 +7,8 @@
 #include "pg_layout.h"
 #include "pg_misc.h"
 #include "pg_mma.h"
-
-#define PG_TRY(expr)            \
-  do {                          \
-    int _s = (expr);            \
-    if (_s != PG_OK) return _s; \
-  } while (0)
+#include "pg_persist.h"
+#include <type_traits>
 
 template <typename T> static inline T* at(void* base, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(base) + off); }
 template <typename T> static inline const T* at(const void* base, size_t off) {
@@ -138,6 +134,30 @@ static int sample_t(const pg_dims* d, int dtype, const float* params, const void
     PG_CHECK_HIP(hipMemcpyAsync(at<float>(ws, w.carry[l]), at<float>(ws, w.h0_32), (size_t)n * Hd * 4, hipMemcpyDeviceToDevice, st));
     PG_CHECK_HIP(hipMemcpyAsync(at<T>(ws, w.hop[l][0]), at<T>(ws, w.h0_op), (size_t)n * Hd * sizeof(T), hipMemcpyDeviceToDevice, st));
   }
+  // the whole decode loop in one group-persistent launch where it is covered (bf16, default decoder, enough rows to
+  // fill the 4-stage pipeline of a group); PG_NO_PERSIST bit 3 / pg_persist_disable force the per-step path below
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    static const long min_rows = getenv("PG_SAMPLE_PERSIST_MIN") ? atol(getenv("PG_SAMPLE_PERSIST_MIN")) : 1024;
+    if (!(persist_off_mask() & 8) && n >= min_rows && max_len >= 2 && dec_sample_persist_supported(Hd, L, d->V, n)) {
+      DecSamplePersist pa;
+      pa.L = L; pa.n = n; pa.T = max_len - 1;
+      for (int l = 0; l < L; ++l) {
+        pa.Whh[l] = at<T>(shadow, so.whh[l]);
+        pa.bhn[l] = params + po.dec_bhh[l] + 2 * Hd;
+        if (l > 0) { pa.Wih[l] = at<T>(shadow, so.wih[l]); pa.bias_gi[l] = at<float>(shadow, so.bias_gi[l]); }
+        pa.hop[l][0] = at<T>(ws, w.hop[l][0]); pa.hop[l][1] = at<T>(ws, w.hop[l][1]);
+        pa.carry[l] = at<float>(ws, w.carry[l]);
+      }
+      pa.table = at<float>(shadow, so.tab_dec); pa.zproj = at<float>(ws, w.zproj);
+      pa.tok = at<int>(ws, w.tok); pa.eos = at<int>(ws, w.eos);
+      pa.fcw = at<T>(shadow, so.fc_w); pa.fcb = at<float>(shadow, so.fc_b);
+      pa.V = d->V; pa.multinomial = multinomial; pa.eos_id = d->eos; pa.max_len = max_len;
+      pa.inv_temp = 1.0f / temp; pa.uniforms = uniforms; pa.seed = seed; pa.row_offset = row_offset;
+      pa.tokens = tokens; pa.end_pads = end_pads;
+      pa.sync = at<unsigned>(ws, w.sync);
+      return launch_dec_sample_persist(pa, st);
+    }
+  }
   using HCfg = TileCfg<T, 128, 64, 8, 4, 1>;
   static_assert(HCfg::SMEM_BYTES >= 128 * 65 * 4, "head kernel LDS too small for the logits tile");
   for (int i = 1; i < max_len; ++i) {
@@ -180,6 +200,7 @@ extern "C" int pg_sample(const pg_dims* d, int dtype, const float* params, const
   PG_TRY(check_dims(d, dtype));
   PG_REQUIRE(params && shadow && ws && z && tokens && end_pads, "pg_sample: NULL buffer");
   PG_REQUIRE(n >= 1, "pg_sample: n must be >= 1");
+  PG_REQUIRE(!persist_poll_failure(), "pg_sample: a persistent kernel of this process gave up waiting for a peer workgroup");
   return dtype == PG_BF16 ? sample_t<bf16_t>(d, dtype, params, shadow, ws, ws_bytes, n, max_len, z, uniforms, seed, row_offset,
                                              temp, multinomial, tokens, end_pads, (hipStream_t)stream)
                           : sample_t<float>(d, dtype, params, shadow, ws, ws_bytes, n, max_len, z, uniforms, seed, row_offset,

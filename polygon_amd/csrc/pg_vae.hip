@@ -171,15 +171,15 @@ static inline long sum_len(const int32_t* l, int B) {
 
 // The persistent recurrence kernels (pg_persist.h) run unless the size is not covered.  PG_NO_PERSIST=<mask> (environment,
 // read once) or pg_persist_disable(mask) force the per-step kernels: bit 0 encoder, bit 1 decoder forward, bit 2 decoder
-// BPTT (A/B timing, and a second implementation for the parity tests).
+// BPTT, bit 3 the sampler (A/B timing, and a second implementation for the parity tests).
 static int g_persist_off = -1;
-static int persist_off_mask() {
-  if (g_persist_off < 0) g_persist_off = getenv("PG_NO_PERSIST") ? atoi(getenv("PG_NO_PERSIST")) & 7 : 0;
+int persist_off_mask() {
+  if (g_persist_off < 0) g_persist_off = getenv("PG_NO_PERSIST") ? atoi(getenv("PG_NO_PERSIST")) & 15 : 0;
   return g_persist_off;
 }
 extern "C" int pg_persist_disable(int mask) {
   const int old = persist_off_mask();
-  if (mask >= 0) g_persist_off = mask & 7;
+  if (mask >= 0) g_persist_off = mask & 15;
   return old;
 }
 static bool use_persistent(int H) { return !(persist_off_mask() & 1) && enc_persist_supported(H); }
