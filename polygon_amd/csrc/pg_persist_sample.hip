@@ -41,7 +41,8 @@ constexpr int TILE0_BYTES = ACT_BYTES / 2 + CARRY_BYTES + 2 * GATE_BYTES;
 constexpr int TOK_BYTES = 16 * PG_SAMPLE_MAX_TS * 4;
 constexpr int SMEM = WIN_BYTES + 2 * TILE_BYTES + 16;
 static_assert(2 * TILE0_BYTES + TOK_BYTES + 16 <= SMEM, "layer-0 layout must fit the common allocation");
-static_assert(16 * 1024 + 16 * 65 * 4 + 16 <= SMEM, "head layout must fit the common allocation");
+static_assert(2 * 16 * 1024 + 16 * 65 * 4 + 16 <= SMEM, "head layout must fit the common allocation");
+static_assert(PG_SAMPLE_MAX_TS <= 2 * NH, "a head workgroup stages at most two tiles per visit");
 
 __device__ __forceinline__ f32x4 mma16(const bf16x8& w, const bf16x8& x, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0);
@@ -314,10 +315,10 @@ __device__ __forceinline__ void layer_body(const DecSamplePersist& a, int g, int
   }
 }
 
-// head workgroup hc of group g: tiles j0 + hc, j0 + hc + NH, ... of every sub-batch
+// head workgroup hc of group g: tiles j0 + hc and j0 + hc + NH of every sub-batch (TS <= 2 * NH)
 __device__ __forceinline__ void head_body(const DecSamplePersist& a, int g, int hc, char* smem) {
-  char* sA = smem;                                                 // [16 rows][1 KB], chunk q of row r at q ^ r
-  float* sl = reinterpret_cast<float*>(smem + 16 * 1024);          // [16][65] logits
+  char* sA = smem;                                                 // 2 x [16 rows][1 KB], chunk q of row r at q ^ r
+  float* sl = reinterpret_cast<float*>(smem + 2 * 16 * 1024);      // [16][65] logits, then exp, then probabilities
   volatile unsigned* sFlagT = reinterpret_cast<volatile unsigned*>(smem + SMEM - 16);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -327,7 +328,14 @@ __device__ __forceinline__ void head_body(const DecSamplePersist& a, int g, int 
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
     wf[ks] = *reinterpret_cast<const bf16x8*>(a.fcw + (long)(wave * 16 + lr) * H + (ks * 4 + lq) * 8);
+  float fb[4];                                                     // bias of this lane's 4 vocabulary entries
+#pragma unroll
+  for (int e = 0; e < 4; ++e) fb[e] = a.fcb[wave * 16 + lq * 4 + e];
+  const float inv_temp = a.inv_temp;
   unsigned* err = a.sync + SYNC_ERR;
+  // softmax / draw mapping: thread = (row tid / 16, entries 4 * (tid % 16) .. + 3); the 16 threads of a row sit in one wave
+  const int srow = tid >> 4, sq = tid & 15;
+  float* y = sl + srow * 65;
 
   for (int t = 0; t < a.T; ++t) {
     const int step = t + 1;                                        // column of the token matrix this step fills
@@ -343,65 +351,94 @@ __device__ __forceinline__ void head_body(const DecSamplePersist& a, int g, int 
       }
       __syncthreads();
       if (*sFlagT == 0u) return;
-      for (int j = j0 + hc; j < j1; j += NH) {
+      // both tiles of the visit are requested at once
+      for (int j = j0 + hc, q = 0; j < j1; j += NH, ++q) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = wave * 4 + i;
           const int b = g + NG * (16 * j + row);
           const int bs = b < n ? b : g;
-          __builtin_amdgcn_global_load_lds((gptr_t)(htop + (long)bs * H + ((lane ^ row) * 8)), (lptr_t)(sA + row * 1024), 16, 0,
-                                           AUX_SC1);
+          __builtin_amdgcn_global_load_lds((gptr_t)(htop + (long)bs * H + ((lane ^ row) * 8)),
+                                           (lptr_t)(sA + q * 16 * 1024 + row * 1024), 16, 0, AUX_SC1);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      for (int j = j0 + hc, q = 0; j < j1; j += NH, ++q) {
+        if (q == 0 && j + NH < j1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // block-uniform
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        const char* A = sA + lr * 1024 + ((lq ^ lr) & 3) * 16;
+        const char* A = sA + q * 16 * 1024 + lr * 1024 + ((lq ^ lr) & 3) * 16;
         const int hi = lr >> 2;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) acc = mma16(wf[ks], *reinterpret_cast<const bf16x8*>(A + ((ks ^ hi) << 6)), acc);
+        // x = (logit + bias) / temp, the arithmetic of sample_head_kernel; entries >= V never win
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sl[lr * 65 + wave * 16 + lq * 4 + e] = acc[e];
+        for (int e = 0; e < 4; ++e) {
+          const int col = wave * 16 + lq * 4 + e;
+          sl[lr * 65 + col] = col < V ? (acc[e] + fb[e]) * inv_temp : -INFINITY;
+        }
         __syncthreads();
-        const int b = g + NG * (16 * j + tid);
-        if (tid < 16 && b < n) {                                   // one lane per row: sample_head_kernel's arithmetic
-          float* y = sl + tid * 65;
-          float mx = -INFINITY;
-          int amax = 0;
-          for (int v = 0; v < V; ++v) {
-            const float x = (y[v] + a.fcb[v]) * a.inv_temp;
-            y[v] = x;
-            if (x > mx) { mx = x; amax = v; }
+        // max and first arg-max of the row (exact in any order), then e = exp(x - max) per entry
+        float x[4], mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[e] = y[sq * 4 + e]; mx = fmaxf(mx, x[e]); }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+        int amax = 1 << 20;
+#pragma unroll
+        for (int e = 3; e >= 0; --e) if (x[e] == mx) amax = sq * 4 + e;
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) amax = min(amax, __shfl_xor(amax, o, 16));
+        int w = amax;
+        if (a.multinomial) {                                       // kernel-uniform
+          float ex[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            ex[e] = sq * 4 + e < V ? __expf(x[e] - mx) : 0.0f;
+            y[sq * 4 + e] = ex[e];
           }
-          int w = amax;
-          if (a.multinomial) {
-            float sum = 0.0f;
-            for (int v = 0; v < V; ++v) {
-              const float e = __expf(y[v] - mx);
-              y[v] = e;
-              sum += e;
-            }
-            float u;
-            if (a.uniforms) u = a.uniforms[(long)(step - 1) * n + b];
-            else {
-              const unsigned long long gr = (unsigned long long)(a.row_offset + b);
-              Philox4 r = philox4x32_10((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)step, 0x5A17u, (uint32_t)a.seed,
-                                        (uint32_t)(a.seed >> 32));
-              u = pg_u01(r.x);
+          __syncthreads();
+          // the sum runs in vocabulary order on one lane per row (fp32 addition is not associative: the per-step kernel's
+          // order is kept, so both paths draw the same token from the same logits)
+          float sum = 0.0f;
+          if (sq == 0) for (int v = 0; v < V; ++v) sum += y[v];
+          sum = __shfl(sum, 0, 16);
+          __syncthreads();
+#pragma unroll
+          for (int e = 0; e < 4; ++e) y[sq * 4 + e] = ex[e] / sum;
+          __syncthreads();
+          if (sq == 0) {
+            const int b = g + NG * (16 * j + srow);
+            float u = 2.0f;
+            if (b < n) {
+              if (a.uniforms) u = a.uniforms[(long)(step - 1) * n + b];
+              else {
+                const unsigned long long gr = (unsigned long long)(a.row_offset + b);
+                Philox4 r = philox4x32_10((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)step, 0x5A17u, (uint32_t)a.seed,
+                                          (uint32_t)(a.seed >> 32));
+                u = pg_u01(r.x);
+              }
             }
             float cdf = 0.0f;
             w = V - 1;
-            for (int v = 0; v < V; ++v) {
-              cdf += y[v] / sum;
-              if (cdf > u) { w = v; break; }
+            bool found = false;
+            for (int v = 0; v < V; ++v) {                          // first v with cdf_v > u
+              cdf += y[v];
+              if (!found && cdf > u) { w = v; found = true; }
             }
           }
-          __hip_atomic_store(a.tok + b, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // published for layer 0
-          if (!a.eos[b]) {                                         // eos[b] is only ever touched by this workgroup
-            a.tokens[(long)b * a.max_len + step] = (uint8_t)w;
-            if (w == a.eos_id) { a.end_pads[b] = step + 1; a.eos[b] = 1; }
+        }
+        if (sq == 0) {
+          const int b = g + NG * (16 * j + srow);
+          if (b < n) {
+            __hip_atomic_store(a.tok + b, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // published for layer 0
+            if (!a.eos[b]) {                                       // eos[b] is only ever touched by this workgroup
+              a.tokens[(long)b * a.max_len + step] = (uint8_t)w;
+              if (w == a.eos_id) { a.end_pads[b] = step + 1; a.eos[b] = 1; }
+            }
           }
         }
-        __syncthreads();                                           // sA / sl are reused by the next tile
+        __syncthreads();                                           // sl is reused by the next tile
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -421,8 +458,19 @@ __global__ __launch_bounds__(256) void dec_sample_persist_kernel(DecSamplePersis
 
 }  // namespace
 
+static int device_cus() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = -1;
+  }
+  return n_cu;
+}
+
+// every workgroup waits for its peers: the grid must be co-resident, one workgroup per CU (pg_persist_dec.hip)
 bool dec_sample_persist_supported(int Hd, int L, int V, long n) {
-  return Hd == H && L == 3 && V <= 64 && n >= 1 && n <= (long)NG * 16 * PG_SAMPLE_MAX_SUB * PG_SAMPLE_MAX_TS;
+  return Hd == H && L == 3 && V <= 64 && n >= 1 && n <= (long)NG * 16 * PG_SAMPLE_MAX_SUB * PG_SAMPLE_MAX_TS &&
+         device_cus() >= NG * (3 * NCU + NH);
 }
 
 int launch_dec_sample_persist(DecSamplePersist& a, hipStream_t stream) {
@@ -430,12 +478,16 @@ int launch_dec_sample_persist(DecSamplePersist& a, hipStream_t stream) {
   PG_REQUIRE(a.sync && a.table && a.tok && a.eos && a.zproj && a.fcw && a.fcb && a.tokens && a.end_pads, "dec_sample_persist: NULL buffer");
   PG_REQUIRE(a.T >= 1 && a.max_len == a.T + 1, "dec_sample_persist: bad step count");
   a.ntile = (int)((((long)a.n + NG - 1) / NG + 15) / 16);
-  // sub-batches: enough of them to keep the 4 stages of a group busy, as large as the row count allows
-  int TS = (a.ntile + PG_SAMPLE_MAX_SUB - 1) / PG_SAMPLE_MAX_SUB;
-  const int want = getenv("PG_SAMPLE_TS") ? atoi(getenv("PG_SAMPLE_TS")) : 12;
-  if (TS < want) TS = want;
+  // Sub-batches: 4 keep the 4 stages of a group busy; more only add visits, and a visit costs every stage its fixed
+  // hand-off (2 us in a layer, ~9 us of latency through the head).  Measured at n = 256 .. 16384: TS = ntile/4 wins
+  // (ntile/2 below 5 tiles, where a visit is all latency); PG_SAMPLE_TS overrides for experiments.
+  int TS = a.ntile <= 4 ? (a.ntile + 1) / 2 : (a.ntile + 3) / 4;
+  if (getenv("PG_SAMPLE_TS")) TS = atoi(getenv("PG_SAMPLE_TS"));
+  const int ts_min = (a.ntile + PG_SAMPLE_MAX_SUB - 1) / PG_SAMPLE_MAX_SUB;
+  if (TS < ts_min) TS = ts_min;
   if (TS > PG_SAMPLE_MAX_TS) TS = PG_SAMPLE_MAX_TS;
   if (TS > a.ntile) TS = a.ntile;
+  if (TS < 1) TS = 1;
   a.TS = TS;
   a.S = (a.ntile + TS - 1) / TS;
   PG_REQUIRE(a.S >= 1 && a.S <= PG_SAMPLE_MAX_SUB, "dec_sample_persist: %d sub-batches", a.S);
@@ -447,15 +499,7 @@ int launch_dec_sample_persist(DecSamplePersist& a, hipStream_t stream) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_done = true;
   }
-  // every workgroup waits for its peers: the grid must be co-resident, one workgroup per CU (pg_persist_dec.hip)
   const int grid = NG * (3 * NCU + NH);
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    PG_CHECK_HIP(hipGetDevice(&dev));
-    PG_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
-  PG_REQUIRE(grid <= n_cu, "dec_sample_persist: %d workgroups cannot be co-resident on %d CUs", grid, n_cu);
   hipLaunchKernelGGL(dec_sample_persist_kernel, dim3(grid), dim3(256), (size_t)SMEM, stream, a);
   PG_CHECK_LAUNCH();
   PG_TRY(persist_fail_mirror(stream));

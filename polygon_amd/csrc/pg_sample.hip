@@ -134,10 +134,11 @@ static int sample_t(const pg_dims* d, int dtype, const float* params, const void
     PG_CHECK_HIP(hipMemcpyAsync(at<float>(ws, w.carry[l]), at<float>(ws, w.h0_32), (size_t)n * Hd * 4, hipMemcpyDeviceToDevice, st));
     PG_CHECK_HIP(hipMemcpyAsync(at<T>(ws, w.hop[l][0]), at<T>(ws, w.h0_op), (size_t)n * Hd * sizeof(T), hipMemcpyDeviceToDevice, st));
   }
-  // the whole decode loop in one group-persistent launch where it is covered (bf16, default decoder, enough rows to
-  // fill the 4-stage pipeline of a group); PG_NO_PERSIST bit 3 / pg_persist_disable force the per-step path below
+  // the whole decode loop in one group-persistent launch where it is covered (bf16, default decoder, at most 16384
+  // rows, a 256-CU device); PG_NO_PERSIST bit 3 / pg_persist_disable force the per-step path below.  Measured faster at
+  // every row count (n = 256: 2.2 vs 6.3 ms, n = 8192: 10.8 vs 21.0 ms per 100-token batch)
   if constexpr (std::is_same<T, bf16_t>::value) {
-    static const long min_rows = getenv("PG_SAMPLE_PERSIST_MIN") ? atol(getenv("PG_SAMPLE_PERSIST_MIN")) : 1024;
+    static const long min_rows = getenv("PG_SAMPLE_PERSIST_MIN") ? atol(getenv("PG_SAMPLE_PERSIST_MIN")) : 1;
     if (!(persist_off_mask() & 8) && n >= min_rows && max_len >= 2 && dec_sample_persist_supported(Hd, L, d->V, n)) {
       DecSamplePersist pa;
       pa.L = L; pa.n = n; pa.T = max_len - 1;

@@ -53,3 +53,55 @@ def test_persistent_matches_per_step(n, p_drop):
     b = _run(model, opt, batch, eps, p_drop, 0)
     assert abs(a[0] - b[0]) <= 1e-6 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-6 * abs(a[1])   # loss sums are fp32 atomics
     assert rel_err(a[2], b[2]) <= 1e-4
+
+
+def _sample(model, mask, n, **kw):
+    L = _lib.lib()
+    old = L.pg_persist_disable(mask)
+    try:
+        tok, ep = model.sample_tokens(n, **kw)
+        torch.cuda.synchronize()
+        return tok.cpu().numpy(), ep.cpu().numpy()
+    finally:
+        L.pg_persist_disable(old)
+
+
+@pytest.mark.parametrize("n,max_len", [(1, 100), (37, 100), (1000, 100), (2049, 23), (8192, 100), (16384, 40)])
+def test_persistent_sampler_matches_per_step(n, max_len):
+    """The one-launch sampler (pg_persist_sample.hip) against the per-step kernels (bit 3 of pg_persist_disable): the
+    same z, the same Philox stream or pre-drawn uniforms -> the same tokens.  The two paths accumulate the gate GEMMs in
+    different orders, so a bf16 state may round differently once in a while and the row then takes another path from
+    there on: the bar is 99.5 % identical rows (measured: 100 % at every size), and the first step - one cell, no
+    accumulated state - identical in every row."""
+    model, _ = build_model(REAL, 31, "bf16", eos_bias=2.0)
+    model.eval()
+    V = len(model.vocabulary)
+    z = torch.randn(n, REAL["Dz"], generator=torch.Generator().manual_seed(n)).cuda()
+    u = torch.rand(max_len - 1, n, generator=torch.Generator().manual_seed(n + 1))
+    for kw in (dict(seed=77, row_offset=12345), dict(uniforms=u), dict(seed=5, temp=0.7)):
+        ref = _sample(model, 8, n, max_len=max_len, z=z, **kw)
+        got = _sample(model, 0, n, max_len=max_len, z=z, **kw)
+        assert got[0].shape == (n, max_len) and (got[0] < V).all()
+        same = (ref[0] == got[0]).all(1) & (ref[1] == got[1])
+        assert same.mean() >= 0.995, (kw.keys(), same.mean())
+        assert (ref[0][:, :2] == got[0][:, :2]).all()
+        # well-formed on its own: nothing past a row's end, end = one past the first eos
+        t, e = got[0].astype(np.int64), got[1].astype(np.int64)
+        cols = np.arange(max_len)[None, :]
+        assert (t[cols >= e[:, None]] == model.pad).all()
+        is_eos = (t == model.eos) & (cols < e[:, None])
+        first = np.where(is_eos.any(1), is_eos.argmax(1), max_len - 1)
+        assert (e == np.minimum(first + 1, max_len)).all()
+    # argmax decoding
+    ref = model_sample_argmax(model, 8, n, max_len, z)
+    got = model_sample_argmax(model, 0, n, max_len, z)
+    assert sum(a == b for a, b in zip(ref, got)) >= 0.995 * n
+
+
+def model_sample_argmax(model, mask, n, max_len, z):
+    L = _lib.lib()
+    old = L.pg_persist_disable(mask)
+    try:
+        return model.sample(n, max_len=max_len, z=z, multinomial=False)
+    finally:
+        L.pg_persist_disable(old)
