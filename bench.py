@@ -238,7 +238,11 @@ def main():
             ds = float(t.item())
         mol_s = reps * args.sample_n * world / ds
         sample = {"metric": "sampled_molecules_per_sec", "value": mol_s, "unit": "molecules/s", "n_per_gpu": args.sample_n,
-                  "max_len": 100, "tflops": mol_s * SAMPLE_FLOP_PER_MOL / 1e12,
+                  "max_len": 100, "ms_per_batch": ds / reps * 1e3,
+                  "kernel": "dec_sample_persist_kernel (the whole decode loop of a batch in one group-persistent launch: "
+                            "3 GRU layers + vocab projection + softmax + inverse-CDF draw)" if args.dtype == "bf16" else
+                            "gru_fwd2_kernel x3 + sample_head_kernel per step",
+                  "tflops": mol_s * SAMPLE_FLOP_PER_MOL / 1e12,
                   "frac_of_mfma_peak": mol_s * SAMPLE_FLOP_PER_MOL / 1e12 / (PEAK[args.dtype] * world)}
 
     if rank == 0:

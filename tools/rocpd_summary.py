@@ -39,7 +39,7 @@ def traffic(db_f, db_w, out_json, dtype):
     out = {}
     for k in sorted(set(F) | set(W)):
         short = k
-        for tag in ("dec_bwd_persist_kernel", "dec_fwd_persist_kernel", "enc_bwd_persist_kernel", "enc_fwd_persist_kernel",
+        for tag in ("dec_sample_persist_kernel", "dec_bwd_persist_kernel", "dec_fwd_persist_kernel", "enc_bwd_persist_kernel", "enc_fwd_persist_kernel",
                     "gru_bwd2_diag_kernel", "gru_fwd2_diag_kernel", "gru_bwd2_kernel", "gru_fwd2_kernel", "gemm_tn_kernel",
                     "gemm_nt_kernel", "colsum_kernel", "ce_kernel", "adam_kernel", "sample_head_kernel"):
             if tag in k:
@@ -59,7 +59,7 @@ def traffic(db_f, db_w, out_json, dtype):
         e["hbm_bytes_per_launch"] = e["fetch_bytes_corrected"] + e["write_bytes"]
     with open(out_json, "w") as f:
         json.dump({"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 2 "
-                           "--warmup 1 --no_cpu_baseline --no_roofline --sample_n 0`; per-launch averages; FETCH_SIZE doubled "
+                           "--warmup 1 --no_cpu_baseline --no_roofline`; per-launch averages; FETCH_SIZE doubled "
                            "(gfx950 correction, MI355X_MICROARCH.md); memory-side-of-L2 counters, Infinity-Cache hits included",
                    dtype: out}, f, indent=1, sort_keys=True)
 
@@ -67,7 +67,7 @@ def traffic(db_f, db_w, out_json, dtype):
 def counters(dbs, out_json, note):
     """Per-kernel averages (per launch, summed over the device's shader engines as rocprofv3 reports them) of every counter
     found in the given --pmc result databases; kernels matched by the names of interest only."""
-    tags = ("dec_bwd_persist_kernel", "dec_fwd_persist_kernel", "enc_bwd_persist_kernel", "enc_fwd_persist_kernel",
+    tags = ("dec_sample_persist_kernel", "dec_bwd_persist_kernel", "dec_fwd_persist_kernel", "enc_bwd_persist_kernel", "enc_fwd_persist_kernel",
             "gemm_tn_kernel", "gemm_nt_kernel", "ce_kernel", "adam_kernel")
     out = {}
     for db in dbs:
