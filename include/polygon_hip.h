@@ -103,7 +103,11 @@ PG_API int pg_clip_adam(long n, float* params, const float* grads, float* exp_av
 /* VAE.sample (vae_model.py:300-358): max_len-1 fused decode steps (3 GRU cells + vocab projection +
  * softmax(y/temp) + inverse-CDF draw or argmax + eos bookkeeping), no early exit, as the reference.
  * uniforms [max_len-1, n] (device) feed the draw of step i at uniforms[(i-1)*n + row]; NULL: Philox
- * keyed by (seed, row_offset + row, step).  tokens uint8 [n,max_len], end_pads int32 [n]. */
+ * keyed by (seed, row_offset + row, step).  tokens uint8 [n,max_len], end_pads int32 [n].
+ * bf16, default decoder (Hd 512, 3 layers), n <= 16384, a device with >= 256 CUs: the whole loop runs as ONE
+ * group-persistent launch (pg_persist_sample.hip) that needs all 256 workgroups resident, so nothing else should be
+ * running on the device during the call; other cases launch 3 cells + 1 head kernel per step.  Both draw the same
+ * tokens from the same inputs. */
 PG_API size_t pg_sample_workspace_bytes(const pg_dims* d, int dtype, int n);
 PG_API int pg_sample(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes, int n,
                      int max_len, const float* z, const float* uniforms, uint64_t seed, long row_offset, float temp,
@@ -142,7 +146,8 @@ PG_API int pg_defer_weight_grads(int on);
 PG_API int pg_deferred_join(void* stream);
 
 /* Test / A-B hook (no reference counterpart): the recurrences run as persistent kernels where the shape is covered
- * (bf16, Hq = 256, Hd = 512); mask bits force the per-step kernels instead: 1 encoder, 2 decoder forward, 4 decoder BPTT.
+ * (bf16, Hq = 256, Hd = 512); mask bits force the per-step kernels instead: 1 encoder, 2 decoder forward, 4 decoder BPTT,
+ * 8 the sampler (pg_sample then launches 3 cells + 1 head kernel per token instead of one kernel per batch).
  * mask < 0 only queries.  Returns the previous mask.  The environment variable PG_NO_PERSIST sets the initial mask. */
 PG_API int pg_persist_disable(int mask);
 
