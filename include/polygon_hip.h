@@ -104,8 +104,8 @@ PG_API int pg_clip_adam(long n, float* params, const float* grads, float* exp_av
  * softmax(y/temp) + inverse-CDF draw or argmax + eos bookkeeping), no early exit, as the reference.
  * uniforms [max_len-1, n] (device) feed the draw of step i at uniforms[(i-1)*n + row]; NULL: Philox
  * keyed by (seed, row_offset + row, step).  tokens uint8 [n,max_len], end_pads int32 [n].
- * bf16, default decoder (Hd 512, 3 layers), n <= 16384, a device with >= 256 CUs: the whole loop runs as ONE
- * group-persistent launch (pg_persist_sample.hip) that needs all 256 workgroups resident, so nothing else should be
+ * bf16, default decoder (Hd 512, 3 layers), a device with >= 256 CUs: the whole loop runs as ONE
+ * group-persistent launch per 16384 rows (pg_persist_sample.hip) that needs all 256 workgroups resident, so nothing else should be
  * running on the device during the call; other cases launch 3 cells + 1 head kernel per step.  Both draw the same
  * tokens from the same inputs. */
 PG_API size_t pg_sample_workspace_bytes(const pg_dims* d, int dtype, int n);

@@ -139,7 +139,8 @@ struct DecSamplePersist {
   const float* fcb = nullptr;                 // [64]
   int V = 0, multinomial = 1, eos_id = 0, max_len = 0;
   float inv_temp = 1.0f;
-  const float* uniforms = nullptr;            // [max_len - 1, n] pre-drawn, or null: Philox(seed, row_offset + row, step)
+  const float* uniforms = nullptr;            // pre-drawn: step i, row b at uniforms[(i-1) * u_stride + b]; null: Philox(seed, row_offset + row, step)
+  long u_stride = 0;
   uint64_t seed = 0;
   long row_offset = 0;
   uint8_t* tokens = nullptr;                  // [n, max_len], initialised (bos, pad...) on entry

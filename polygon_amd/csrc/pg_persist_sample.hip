@@ -411,7 +411,7 @@ __device__ __forceinline__ void head_body(const DecSamplePersist& a, int g, int 
             const int b = g + NG * (16 * j + srow);
             float u = 2.0f;
             if (b < n) {
-              if (a.uniforms) u = a.uniforms[(long)(step - 1) * n + b];
+              if (a.uniforms) u = a.uniforms[(long)(step - 1) * a.u_stride + b];
               else {
                 const unsigned long long gr = (unsigned long long)(a.row_offset + b);
                 Philox4 r = philox4x32_10((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)step, 0x5A17u, (uint32_t)a.seed,

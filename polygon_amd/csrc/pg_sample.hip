@@ -139,24 +139,29 @@ static int sample_t(const pg_dims* d, int dtype, const float* params, const void
   // every row count (n = 256: 2.2 vs 6.3 ms, n = 8192: 10.8 vs 21.0 ms per 100-token batch)
   if constexpr (std::is_same<T, bf16_t>::value) {
     static const long min_rows = getenv("PG_SAMPLE_PERSIST_MIN") ? atol(getenv("PG_SAMPLE_PERSIST_MIN")) : 1;
-    if (!(persist_off_mask() & 8) && n >= min_rows && max_len >= 2 && dec_sample_persist_supported(Hd, L, d->V, n)) {
-      DecSamplePersist pa;
-      pa.L = L; pa.n = n; pa.T = max_len - 1;
-      for (int l = 0; l < L; ++l) {
-        pa.Whh[l] = at<T>(shadow, so.whh[l]);
-        pa.bhn[l] = params + po.dec_bhh[l] + 2 * Hd;
-        if (l > 0) { pa.Wih[l] = at<T>(shadow, so.wih[l]); pa.bias_gi[l] = at<float>(shadow, so.bias_gi[l]); }
-        pa.hop[l][0] = at<T>(ws, w.hop[l][0]); pa.hop[l][1] = at<T>(ws, w.hop[l][1]);
-        pa.carry[l] = at<float>(ws, w.carry[l]);
+    constexpr long CHUNK = 16384;   // rows per launch (dec_sample_persist_supported); larger batches run chunk after chunk
+    if (!(persist_off_mask() & 8) && n >= min_rows && max_len >= 2 && dec_sample_persist_supported(Hd, L, d->V, n < CHUNK ? n : CHUNK)) {
+      for (long r0 = 0; r0 < n; r0 += CHUNK) {
+        DecSamplePersist pa;
+        pa.L = L; pa.n = (int)(n - r0 < CHUNK ? n - r0 : CHUNK); pa.T = max_len - 1;
+        for (int l = 0; l < L; ++l) {
+          pa.Whh[l] = at<T>(shadow, so.whh[l]);
+          pa.bhn[l] = params + po.dec_bhh[l] + 2 * Hd;
+          if (l > 0) { pa.Wih[l] = at<T>(shadow, so.wih[l]); pa.bias_gi[l] = at<float>(shadow, so.bias_gi[l]); }
+          pa.hop[l][0] = at<T>(ws, w.hop[l][0]) + r0 * Hd; pa.hop[l][1] = at<T>(ws, w.hop[l][1]) + r0 * Hd;
+          pa.carry[l] = at<float>(ws, w.carry[l]) + r0 * Hd;
+        }
+        pa.table = at<float>(shadow, so.tab_dec); pa.zproj = at<float>(ws, w.zproj) + r0 * 3 * Hd;
+        pa.tok = at<int>(ws, w.tok) + r0; pa.eos = at<int>(ws, w.eos) + r0;
+        pa.fcw = at<T>(shadow, so.fc_w); pa.fcb = at<float>(shadow, so.fc_b);
+        pa.V = d->V; pa.multinomial = multinomial; pa.eos_id = d->eos; pa.max_len = max_len;
+        pa.inv_temp = 1.0f / temp; pa.seed = seed; pa.row_offset = row_offset + r0;
+        pa.uniforms = uniforms ? uniforms + r0 : nullptr; pa.u_stride = n;
+        pa.tokens = tokens + r0 * max_len; pa.end_pads = end_pads + r0;
+        pa.sync = at<unsigned>(ws, w.sync);
+        PG_TRY(launch_dec_sample_persist(pa, st));
       }
-      pa.table = at<float>(shadow, so.tab_dec); pa.zproj = at<float>(ws, w.zproj);
-      pa.tok = at<int>(ws, w.tok); pa.eos = at<int>(ws, w.eos);
-      pa.fcw = at<T>(shadow, so.fc_w); pa.fcb = at<float>(shadow, so.fc_b);
-      pa.V = d->V; pa.multinomial = multinomial; pa.eos_id = d->eos; pa.max_len = max_len;
-      pa.inv_temp = 1.0f / temp; pa.uniforms = uniforms; pa.seed = seed; pa.row_offset = row_offset;
-      pa.tokens = tokens; pa.end_pads = end_pads;
-      pa.sync = at<unsigned>(ws, w.sync);
-      return launch_dec_sample_persist(pa, st);
+      return PG_OK;
     }
   }
   using HCfg = TileCfg<T, 128, 64, 8, 4, 1>;

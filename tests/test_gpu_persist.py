@@ -66,7 +66,7 @@ def _sample(model, mask, n, **kw):
         L.pg_persist_disable(old)
 
 
-@pytest.mark.parametrize("n,max_len", [(1, 100), (37, 100), (1000, 100), (2049, 23), (8192, 100), (16384, 40)])
+@pytest.mark.parametrize("n,max_len", [(1, 100), (37, 100), (1000, 100), (2049, 23), (8192, 100), (16384, 40), (20000, 12)])
 def test_persistent_sampler_matches_per_step(n, max_len):
     """The one-launch sampler (pg_persist_sample.hip) against the per-step kernels (bit 3 of pg_persist_disable): the
     same z, the same Philox stream or pre-drawn uniforms -> the same tokens.  The two paths accumulate the gate GEMMs in
