@@ -91,7 +91,7 @@ template <int H, bool TOP> struct BwdGeo {
   static constexpr int KSP = 16;                 // K steps per part
   static constexpr int KS_REG_UP = 2 * H / 32;   // upper-layer K steps held in registers (r, z columns); the rest in LDS
   static constexpr int NCU = H / 64;
-  static constexpr int ROWW = H * 2 + 16;        // LDS row of the n-gate columns of W_ih_up^T (padded)
+  static constexpr int ROWW = H * 2;             // LDS row of the n-gate columns of W_ih_up^T: unpadded, chunk q of row u at q ^ (u & 15)
   static constexpr int WN_BYTES = TOP ? 0 : 64 * ROWW;
   static constexpr int NSLOT = TOP ? 8 : 5;
   static constexpr int D = NSLOT - 2;            // parts in flight behind the one being consumed
@@ -131,7 +131,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
       wu[ks] = *reinterpret_cast<const bf16x8*>(WihT + (long)(uw + lr) * 3 * H + (ks * 4 + lq) * 8);
     for (int id = tid; id < 64 * (H / 8); id += 256) {
       const int u = id / (H / 8), ch = id % (H / 8);
-      *reinterpret_cast<uint4*>(sWn + u * ROWW + ch * 16) =
+      *reinterpret_cast<uint4*>(sWn + u * ROWW + ((ch ^ (u & 15)) << 4)) =
           *reinterpret_cast<const uint4*>(WihT + (long)(c * 64 + u) * 3 * H + 2 * H + ch * 8);
     }
   }
@@ -299,14 +299,14 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
           }
           {
             const char* A = part_begin();
-            const char* Wn = sWn + (wave * 16 + lr) * ROWW + lq * 16;
+            const char* Wn = sWn + (wave * 16 + lr) * ROWW + ((lq ^ lr) & 3) * 16;   // chunk ks*4+lq of row lr sits at (ks*4+lq) ^ lr
             if (!(a.dbg & 2)) {
             // activation and weight fragments both come from LDS here: groups of 4 K-steps, one group ahead
             bf16x8 xa[4], wa[4], xb[4], wb[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               xa[i] = *reinterpret_cast<const bf16x8*>(A + ((i ^ hi) << 6));
-              wa[i] = *reinterpret_cast<const bf16x8*>(Wn + i * 64);
+              wa[i] = *reinterpret_cast<const bf16x8*>(Wn + ((i ^ hi) << 6));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -317,10 +317,10 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
                   const int ks = (gk + 1) * 4 + i;
                   if (gk & 1) {
                     xa[i] = *reinterpret_cast<const bf16x8*>(A + ((ks ^ hi) << 6));
-                    wa[i] = *reinterpret_cast<const bf16x8*>(Wn + ks * 64);
+                    wa[i] = *reinterpret_cast<const bf16x8*>(Wn + ((ks ^ hi) << 6));
                   } else {
                     xb[i] = *reinterpret_cast<const bf16x8*>(A + ((ks ^ hi) << 6));
-                    wb[i] = *reinterpret_cast<const bf16x8*>(Wn + ks * 64);
+                    wb[i] = *reinterpret_cast<const bf16x8*>(Wn + ((ks ^ hi) << 6));
                   }
                 }
               }

@@ -88,7 +88,7 @@ __device__ __forceinline__ bool wait_ge(unsigned* p, unsigned target, unsigned* 
 template <int H> struct DecGeo {
   static constexpr int KS = H / 32;             // MFMA K steps over a K = H contraction
   static constexpr int NCU = H / 64;            // workgroups (unit slices) per layer
-  static constexpr int ROWW = H * 2 + 16;       // W_in row in LDS (padded)
+  static constexpr int ROWW = H * 2;            // W_in row in LDS: unpadded, 16-byte chunk q of row u at position q ^ (u & 15)
   static constexpr int WIN_BYTES = 64 * ROWW;
   static constexpr int ACT_BYTES = 16 * 2 * H * 2;    // activation tile rows [h_{t-1} | x], unpadded (swizzled); layer 0 uses half
   static constexpr int CARRY_BYTES = 16 * 64 * 4;     // fp32 state slice of the tile's rows (this workgroup's 64 units)
@@ -136,7 +136,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
         wi[gt][ks] = *reinterpret_cast<const bf16x8*>(Wih + (long)(gt * H + uw + lr) * H + (ks * 4 + lq) * 8);
     for (int id = tid; id < 64 * (H / 8); id += 256) {
       const int u = id / (H / 8), ch = id % (H / 8);
-      *reinterpret_cast<uint4*>(sWin + u * ROWW + ch * 16) =
+      *reinterpret_cast<uint4*>(sWin + u * ROWW + ((ch ^ (u & 15)) << 4)) =
           *reinterpret_cast<const uint4*>(Wih + (long)(2 * H + c * 64 + u) * H + ch * 8);
     }
   }
@@ -300,12 +300,12 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
         }
       }
       if constexpr (!L0) if (!(a.dbg & 2)) {
-        const char* Wn = sWin + (wave * 16 + lr) * ROWW + lq * 16;
+        const char* Wn = sWin + (wave * 16 + lr) * ROWW + ((lq ^ lr) & 3) * 16;   // chunk ks*4+lq of row lr sits at (ks*4+lq) ^ lr
         bf16x8 fx[KS / 4][4], fw[KS / 4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           fx[0][i] = *reinterpret_cast<const bf16x8*>(A + 1024 + ((i ^ hi) << 6));
-          fw[0][i] = *reinterpret_cast<const bf16x8*>(Wn + i * 64);
+          fw[0][i] = *reinterpret_cast<const bf16x8*>(Wn + ((i ^ hi) << 6));
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -315,7 +315,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
             for (int i = 0; i < 4; ++i) {
               const int ks = (gk + 1) * 4 + i;
               fx[gk + 1][i] = *reinterpret_cast<const bf16x8*>(A + 1024 + ((ks ^ hi) << 6));
-              fw[gk + 1][i] = *reinterpret_cast<const bf16x8*>(Wn + ks * 64);
+              fw[gk + 1][i] = *reinterpret_cast<const bf16x8*>(Wn + ((ks ^ hi) << 6));
             }
           }
           __builtin_amdgcn_sched_barrier(0);

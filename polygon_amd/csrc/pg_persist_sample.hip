@@ -31,7 +31,7 @@ constexpr int SYNC_ERR = NG * NSTAGE * PG_SAMPLE_MAX_SUB * SYNC_STRIDE;
 static_assert(SYNC_ERR + 1 <= PG_SAMPLE_SYNC_WORDS, "sync block too small");
 constexpr unsigned SPIN_LIMIT = 1u << 21;
 constexpr int AUX_SC1 = 16;
-constexpr int ROWW = H * 2 + 16;
+constexpr int ROWW = H * 2;   // W_in row in LDS: unpadded, 16-byte chunk q of row u at position q ^ (u & 15)
 constexpr int WIN_BYTES = 64 * ROWW;
 constexpr int ACT_BYTES = 16 * 2 * H * 2;
 constexpr int CARRY_BYTES = 16 * 64 * 4;
@@ -108,7 +108,7 @@ __device__ __forceinline__ void layer_body(const DecSamplePersist& a, int g, int
         wi[gt][ks] = *reinterpret_cast<const bf16x8*>(Wih + (long)(gt * H + uw + lr) * H + (ks * 4 + lq) * 8);
     for (int id = tid; id < 64 * (H / 8); id += 256) {
       const int u = id / (H / 8), ch = id % (H / 8);
-      *reinterpret_cast<uint4*>(sWin + u * ROWW + ch * 16) =
+      *reinterpret_cast<uint4*>(sWin + u * ROWW + ((ch ^ (u & 15)) << 4)) =
           *reinterpret_cast<const uint4*>(Wih + (long)(2 * H + c * 64 + u) * H + ch * 8);
     }
   }
@@ -240,12 +240,12 @@ __device__ __forceinline__ void layer_body(const DecSamplePersist& a, int g, int
           }
         }
         if constexpr (!L0) {
-          const char* Wn = sWin + (wave * 16 + lr) * ROWW + lq * 16;
+          const char* Wn = sWin + (wave * 16 + lr) * ROWW + ((lq ^ lr) & 3) * 16;   // chunk ks*4+lq of row lr sits at (ks*4+lq) ^ lr
           bf16x8 fx[KS / 4][4], fw[KS / 4][4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             fx[0][i] = *reinterpret_cast<const bf16x8*>(A + 1024 + ((i ^ hi) << 6));
-            fw[0][i] = *reinterpret_cast<const bf16x8*>(Wn + i * 64);
+            fw[0][i] = *reinterpret_cast<const bf16x8*>(Wn + ((i ^ hi) << 6));
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -255,7 +255,7 @@ __device__ __forceinline__ void layer_body(const DecSamplePersist& a, int g, int
               for (int i = 0; i < 4; ++i) {
                 const int ks = (gk + 1) * 4 + i;
                 fx[gk + 1][i] = *reinterpret_cast<const bf16x8*>(A + 1024 + ((ks ^ hi) << 6));
-                fw[gk + 1][i] = *reinterpret_cast<const bf16x8*>(Wn + ks * 64);
+                fw[gk + 1][i] = *reinterpret_cast<const bf16x8*>(Wn + ((ks ^ hi) << 6));
               }
             }
             __builtin_amdgcn_sched_barrier(0);
