@@ -5,6 +5,7 @@
 #include "pg_gru.h"
 #include "pg_layout.h"
 #include "pg_misc.h"
+#include "pg_mma.h"
 #include "pg_persist.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -349,6 +350,76 @@ extern "C" int pg_encoder_fwd(const pg_dims* d, int dtype, const float* params, 
 // ===================================================================================================
 // decoder forward
 // ===================================================================================================
+// Fused vocabulary projection + log-softmax + cross entropy + dlogits (vae_model.py:287-293: decoder_fc, then
+// F.cross_entropy over the packed rows with ignore_index = pad).  One workgroup = 128 packed rows: logits tile on MFMA
+// (W_fc is 64 padded rows: the whole vocabulary is one N tile), parked in LDS, then one wave per row does what ce_kernel
+// does - max / sum-exp by wave reductions, loss and count accumulated per block (two atomics per block), softmax - onehot
+// written as the operand of the backward GEMMs.  The fp32 logits are still written (the API hands them out); nothing
+// reads them back on the training path.
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NTHREADS) void fc_ce_kernel(const typename Cfg::T* __restrict__ htop, long N, int H,
+                                                               const typename Cfg::T* __restrict__ fcw,
+                                                               const float* __restrict__ fcb, int V, int Vp,
+                                                               const int* __restrict__ tgt, int pad,
+                                                               float* __restrict__ logits, typename Cfg::T* __restrict__ dlogits,
+                                                               float* __restrict__ scal) {
+  using T = typename Cfg::T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int m0 = blockIdx.x * Cfg::BM;
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  {
+    const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = zacc;
+  }
+  RowSrc<T> as{htop, H, m0, (int)N};
+  RowSrc<T> bs{fcw, H, 0, Cfg::BN};
+  mma_mainloop_nt<Cfg, Cfg::TN, 0>(acc, as, bs, H, smem);
+  float* sl = reinterpret_cast<float*>(smem);  // [BM][65]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+#pragma unroll
+  for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < Cfg::TN; ++tn)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        sl[Cfg::row_of(wm, tm, reg, lane) * 65 + Cfg::col_in_group(wn, tn, lane & 31)] = acc[tm][tn][reg];
+  __syncthreads();
+  constexpr int NW = Cfg::NTHREADS / 64;
+  const float bias = lane < Vp ? fcb[lane] : 0.0f;
+  float loss = 0.0f, cnt = 0.0f;
+  for (int r = wave; r < Cfg::BM; r += NW) {
+    const long row = (long)m0 + r;
+    if (row >= N) break;
+    const float y = sl[r * 65 + lane] + bias;
+    if (logits && lane < Vp) logits[row * Vp + lane] = y;
+    const float x = lane < V ? y : -INFINITY;
+    const float mx = wave_max(x);
+    const float e = lane < V ? __expf(x - mx) : 0.0f;
+    const float s = wave_sum(e);
+    const int tg = tgt[row];
+    const bool w = tg != pad;
+    const float xt = __shfl(x, tg < 64 ? tg : 0, 64);
+    if (w) { loss += __logf(s) + mx - xt; cnt += 1.0f; }
+    if (dlogits && lane < Vp) {
+      const float p = e / s;
+      dlogits[row * Vp + lane] = from_f32<T>(w && lane < V ? p - (lane == tg ? 1.0f : 0.0f) : 0.0f);
+    }
+  }
+  __syncthreads();   // the logits tile is dead: its first words carry the per-wave partial sums
+  if (lane == 0) { sl[wave] = loss; sl[16 + wave] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.0f, c = 0.0f;
+    for (int w = 0; w < NW; ++w) { a += sl[w]; c += sl[16 + w]; }
+    atomicAdd(scal + SC_CE_SUM, a);
+    atomicAdd(scal + SC_CE_CNT, c);
+  }
+}
+
 template <typename T>
 static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes, int B,
                          int Tmax, const int32_t* d_tokens, const int32_t* lens, const float* z, const pg_dp* dp, float p_drop,
@@ -460,14 +531,23 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
     PG_TRY(launch_gru_fwd_diag<T>(dg, st));
   }
   prof_end(0, pslot, st, sd.T + L - 1, pflop);
-  {  // vocab projection
-    GemmEpi<T> e;
-    e.bias = at<float>(shadow, so.fc_b); e.C32 = at<float>(ws, w.d_logits); e.ldc = Vp;
-    PG_TRY(launch_gemm_nt<T>(at<T>(ws, w.d_hseq[L - 1]), Hd, at<T>(shadow, so.fc_w), Hd, (int)Nd, Vp, Hd, e, st));
+  if (Vp == 64 && !getenv("PG_NO_FUSED_CE")) {   // vocab projection + log-softmax + CE + dlogits in one kernel
+    using FCfg = TileCfg<T, 128, 64, 8, 4, 1>;
+    static_assert(FCfg::SMEM_BYTES >= 128 * 65 * 4, "fc_ce kernel: LDS too small for the logits tile");
+    PG_LAUNCH_BIG_SMEM(fc_ce_kernel<FCfg>, dim3(cdiv(Nd, FCfg::BM)), dim3(FCfg::NTHREADS), FCfg::SMEM_BYTES, st,
+                       at<T>(ws, w.d_hseq[L - 1]), Nd, Hd, at<T>(shadow, so.fc_w), at<float>(shadow, so.fc_b), d->V, Vp,
+                       at<int>(ws, w.dec_tgt), d->pad, at<float>(ws, w.d_logits), save ? at<T>(ws, w.d_dlogits) : (T*)nullptr, scal);
+    PG_CHECK_LAUNCH();
+  } else {
+    {  // vocab projection
+      GemmEpi<T> e;
+      e.bias = at<float>(shadow, so.fc_b); e.C32 = at<float>(ws, w.d_logits); e.ldc = Vp;
+      PG_TRY(launch_gemm_nt<T>(at<T>(ws, w.d_hseq[L - 1]), Hd, at<T>(shadow, so.fc_w), Hd, (int)Nd, Vp, Hd, e, st));
+    }
+    hipLaunchKernelGGL(ce_kernel<T>, dim3(std::min<int>(cdiv(Nd, 4), 1024)), dim3(256), 0, st, at<float>(ws, w.d_logits), at<int>(ws, w.dec_tgt), Nd,
+                       d->V, Vp, d->pad, save ? at<T>(ws, w.d_dlogits) : (T*)nullptr, scal);
+    PG_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(ce_kernel<T>, dim3(std::min<int>(cdiv(Nd, 4), 1024)), dim3(256), 0, st, at<float>(ws, w.d_logits), at<int>(ws, w.dec_tgt), Nd,
-                     d->V, Vp, d->pad, save ? at<T>(ws, w.d_dlogits) : (T*)nullptr, scal);
-  PG_CHECK_LAUNCH();
   hipLaunchKernelGGL(finalize_ce_kernel, dim3(1), dim3(1), 0, st, scal, dp ? dp->ce_count : 0.0f, recon);
   PG_CHECK_LAUNCH();
   if (logits_packed) *logits_packed = at<float>(ws, w.d_logits);
