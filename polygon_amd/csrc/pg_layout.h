@@ -147,7 +147,10 @@ static inline TrainWs train_ws_layout(const pg_dims* d, int dtype, long B, long 
   w.scalars = take(SC_N * 4);
   w.sync = take(2064 * 4);   // PG_PERSIST_SYNC_WORDS (pg_persist.h)
   w.e_carry = take(B * Hq * 4); w.e_hop[0] = take(B * Hq * es); w.e_hop[1] = take(B * Hq * es);
-  for (int i = 0; i < 5; ++i) w.e_sv[i] = take(Ne * Hq * es);
+  // r, z, n, hn of the encoder are kept in the persistent kernels' lane-major order, one 16-row slot per (step, block),
+  // steps padded by 16 rows (pg_persist.hip): up to 16 * (max steps 512 + 1) rows more than the packed count
+  for (int i = 0; i < 4; ++i) w.e_sv[i] = take((Ne + 16 * 513) * Hq * es);
+  w.e_sv[4] = take(Ne * Hq * es);
   w.e_hfin_op = take(B * Hq * es); w.e_mulv = take(B * 2 * Dz * 4); w.e_eps = take(B * Dz * 4); w.e_zop = take(B * Dz * es);
   w.d_zop = take(B * Dz * es); w.d_zproj = take(B * 3 * Hd * 4); w.d_h0_32 = take(B * Hd * 4); w.d_h0_op = take(B * Hd * es);
   for (int l = 0; l < d->L; ++l) {

@@ -5,14 +5,30 @@
 // so the accumulator tile is [unit][sequence]: lane (lr = lane & 15, lq = lane >> 4) holds units 4lq..4lq+3 of sequence lr.
 // Four consecutive units per lane make every global access of the epilogue an 8-byte (bf16x4) or 16-byte (float4) one.
 #include <hip/hip_runtime.h>
+#include "pg_mma.h"
 #include "pg_persist.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 namespace {
 
 constexpr int PR = 16;   // sequences per block
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0), i.e. for the acknowledgement
+// of the step's global stores (2-3 us each on this chip) and for the prefetched loads of the next step - per step of a
+// ~1 us recurrence.  What the waves exchange at these barriers is the LDS tile, nothing else.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// 8-byte store through a buffer descriptor: lanes whose sequence is over get an offset beyond the descriptor's range and
+// the hardware drops them, so every wave issues the same number of stores and hipcc's vmcnt bookkeeping stays exact
+__device__ __forceinline__ void store_b64(__amdgpu_buffer_rsrc_t r, bool ok, long elem, const bf16x4& v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)(ok ? (unsigned)(elem * 2) : 0x80000000u), 0, 0);
+}
 
 __device__ __forceinline__ f32x4 mma16(const bf16x8& w, const bf16x8& x, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, c, 0, 0, 0);
@@ -27,12 +43,17 @@ template <int H> struct PersistGeo {
   static constexpr int NW = H / 32;              // waves
   static constexpr int NTH = 64 * NW;
   static constexpr int KS_H = H / 32;            // MFMA K steps over a K = H contraction
-  static constexpr int ROWB_H = H * 2 + 16;      // padded LDS row of H bf16
-  static constexpr int ROWB_3H = 3 * H * 2 + 16;
+  static constexpr int ROWB_H = H * 2 + 16;      // forward kernel: padded LDS row of H bf16
+  static constexpr int ROWB_X = H * 2;           // backward kernel: unpadded, 16-byte chunk q of row r at position q ^ (r & 15)
+  static constexpr int ROWB_3H = 3 * H * 2;      // the same layout (XOR inside each aligned group of 16 chunks)
   static constexpr int WN_BYTES = H * ROWB_H;    // n-gate weight rows kept in LDS
   static constexpr int FWD_SMEM = WN_BYTES + 2 * PR * ROWB_H;
-  static constexpr int BWD_SMEM = WN_BYTES + PR * ROWB_3H;
+  static constexpr int BWD_SMEM = H * ROWB_X + PR * ROWB_3H;
 };
+
+// first element of the lane-major slot of (step t, block at row0): packed offset of the step + 16 rows of padding per
+// step, so that the 16-row slot of a step's last, partial block never reaches the next step's slots
+__device__ __forceinline__ long sv_slot(int off_t, int t, int row0, int H) { return (long)(off_t + 16 * t + row0) * H; }
 
 // steps this block runs = length of its longest (first) sequence = #t with B_t > row0 (B_t is non-increasing)
 __device__ __forceinline__ int block_steps(const Sched& sd, int row0) {
@@ -146,13 +167,17 @@ __global__ __launch_bounds__(PersistGeo<H>::NTH) void enc_fwd_persist_kernel(Enc
         if (live) h[nt][i] = (1.0f - z[i]) * n[i] + z[i] * hp[i];
       }
       const int u = u0 + nt * 16;
-      if (live && a.sv_r) {
-        const long s = (long)(o + b) * H + u;
-        *reinterpret_cast<bf16x4*>(a.sv_r + s) = to_bf16x4(r);
-        *reinterpret_cast<bf16x4*>(a.sv_z + s) = to_bf16x4(z);
-        *reinterpret_cast<bf16x4*>(a.sv_n + s) = to_bf16x4(n);
-        *reinterpret_cast<bf16x4*>(a.sv_hn + s) = to_bf16x4(hn);
-        *reinterpret_cast<bf16x4*>(a.sv_hprev + s) = to_bf16x4(hp);
+      if (a.sv_r) {   // kernel-uniform
+        // r, z, n, hn are read back by enc_bwd_persist_kernel only, lane for lane: they are stored in LANE order (512
+        // contiguous bytes per wave instruction) in the 16-row slot of (step, block).  The row-major form of the same
+        // data is 16 rows x 32 bytes per instruction, which the address path serialises (16 cache lines): 10 such
+        // stores per wave and step were most of the step's time.  h_prev stays row-major: it is a GEMM operand.
+        const long sl = sv_slot(o, t, row0, H) + ((wave * 2 + nt) * 64 + lane) * 4;
+        *reinterpret_cast<bf16x4*>(a.sv_r + sl) = to_bf16x4(r);
+        *reinterpret_cast<bf16x4*>(a.sv_z + sl) = to_bf16x4(z);
+        *reinterpret_cast<bf16x4*>(a.sv_n + sl) = to_bf16x4(n);
+        *reinterpret_cast<bf16x4*>(a.sv_hn + sl) = to_bf16x4(hn);
+        if (live) *reinterpret_cast<bf16x4*>(a.sv_hprev + (long)(o + b) * H + u) = to_bf16x4(hp);
       }
       *reinterpret_cast<bf16x4*>(An + u * 2) = to_bf16x4(h[nt]);
     }
@@ -180,10 +205,10 @@ __global__ __launch_bounds__(PersistGeo<H>::NTH) void enc_fwd_persist_kernel(Enc
 template <int H>
 __global__ __launch_bounds__(PersistGeo<H>::NTH) void enc_bwd_persist_kernel(EncBwdPersist a, Sched sd) {
   using G = PersistGeo<H>;
-  constexpr int KS = G::KS_H, ROWB = G::ROWB_H, ROWA = G::ROWB_3H;
+  constexpr int KS = G::KS_H, ROWB = G::ROWB_X, ROWA = G::ROWB_3H;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sWn = smem;                 // [H][ROWB]: W_hh^T[j][2H + k]
-  char* sA = smem + G::WN_BYTES;    // [PR][ROWA]: dGH_{t+1} of the block's sequences (bf16)
+  char* sA = smem + H * ROWB;       // [PR][ROWA]: dGH_{t+1} of the block's sequences (bf16)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
@@ -200,7 +225,7 @@ __global__ __launch_bounds__(PersistGeo<H>::NTH) void enc_bwd_persist_kernel(Enc
       wreg[nt][ks] = *reinterpret_cast<const bf16x8*>(a.WhhT + (long)(wave * 32 + nt * 16 + lr) * 3 * H + (ks * 4 + lq) * 8);
   for (int c = tid; c < H * (H / 8); c += G::NTH) {
     const int u = c / (H / 8), ch = c % (H / 8);
-    *reinterpret_cast<uint4*>(sWn + u * ROWB + ch * 16) = *reinterpret_cast<const uint4*>(a.WhhT + (long)u * 3 * H + 2 * H + ch * 8);
+    *reinterpret_cast<uint4*>(sWn + u * ROWB + ((ch ^ (u & 15)) << 4)) = *reinterpret_cast<const uint4*>(a.WhhT + (long)u * 3 * H + 2 * H + ch * 8);
   }
   for (int c = tid; c < PR * ROWA / 16; c += G::NTH) reinterpret_cast<uint4*>(sA)[c] = make_uint4(0, 0, 0, 0);
 
@@ -209,12 +234,14 @@ __global__ __launch_bounds__(PersistGeo<H>::NTH) void enc_bwd_persist_kernel(Enc
     // sequences that are over at step t read row 0 of the step (valid memory, values unused)
     const int o = t >= 0 ? sd.off[t] : 0, Bt = t >= 0 ? sd.off[t + 1] - o : 0;
     const long base = (long)(o + (b < Bt ? b : 0)) * H + u0;
+    const int tt = t >= 0 ? t : 0;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      s.r[nt] = *reinterpret_cast<const bf16x4*>(a.sv_r + base + nt * 16);
-      s.z[nt] = *reinterpret_cast<const bf16x4*>(a.sv_z + base + nt * 16);
-      s.n[nt] = *reinterpret_cast<const bf16x4*>(a.sv_n + base + nt * 16);
-      s.hn[nt] = *reinterpret_cast<const bf16x4*>(a.sv_hn + base + nt * 16);
+      const long sl = sv_slot(o, tt, row0, H) + ((wave * 2 + nt) * 64 + lane) * 4;   // lane order, as the forward kernel wrote it
+      s.r[nt] = *reinterpret_cast<const bf16x4*>(a.sv_r + sl);
+      s.z[nt] = *reinterpret_cast<const bf16x4*>(a.sv_z + sl);
+      s.n[nt] = *reinterpret_cast<const bf16x4*>(a.sv_n + sl);
+      s.hn[nt] = *reinterpret_cast<const bf16x4*>(a.sv_hn + sl);
       s.hp[nt] = *reinterpret_cast<const bf16x4*>(a.sv_hprev + base + nt * 16);
     }
   };
@@ -223,30 +250,42 @@ __global__ __launch_bounds__(PersistGeo<H>::NTH) void enc_bwd_persist_kernel(Enc
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int i = 0; i < 4; ++i) dhc[nt][i] = 0.0f;
-  Saved sv;
+  Saved sv, sv1;   // saved activations of steps t and t-1: fetched two steps ahead (an HBM miss outlasts a step)
   if (Tb > 0) load_saved(Tb - 1, sv);
+  if (Tb > 0) load_saved(Tb - 2, sv1);
+  const __amdgpu_buffer_rsrc_t r_dGI = pg_make_rsrc(a.dGI), r_dGH = pg_make_rsrc(a.dGH);
+  // gradient injected at this lane's sequence's last step: loaded once.  A load inside the step loop - even a
+  // conditional one - makes hipcc wait for vmcnt(0) at the join, i.e. for the previous step's store acknowledgements and
+  // the prefetched activations, every step.
+  f32x4 inj[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+    inj[nt] = b < a.B ? *reinterpret_cast<const f32x4*>(a.dhfin + (long)b * H + u0 + nt * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
-  for (int t = Tb - 1; t >= 0; --t) {
-    Saved svn;
-    load_saved(t - 1, svn);   // prefetch the next (earlier) step; t-1 = -1 reads step 0's first row, unused
+  // one step; `sv` holds the saved activations of step t (requested two steps ago), `svn` receives those of step t-2.
+  // The three register sets rotate by NAME (the loop below is unrolled by three): a register copy of a set still in flight
+  // would make hipcc wait for it - and, vmcnt being one in-order counter, for every store issued before it.
+  auto step = [&](int t, const Saved& sv, Saved& svn) __attribute__((always_inline)) {
+    load_saved(t - 2, svn);   // t - 2 < 0 reads step 0's first row, unused
     f32x4 acc[2];
     acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
     acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (t + 1 < Tb) {   // block-uniform: the first step has no recurrent gradient yet
-      const char* A = sA + lr * ROWA + lq * 16;
-      const char* Wn = sWn + (wave * 32 + lr) * ROWB + lq * 16;
+      const int hi = lr >> 2;   // chunk q of row lr sits at q ^ lr (see the forward kernel)
+      const char* A = sA + lr * ROWA + ((lq ^ lr) & 3) * 16;
+      const char* Wn = sWn + (wave * 32 + lr) * ROWB + ((lq ^ lr) & 3) * 16;
 #pragma unroll
       for (int ks = 0; ks < 2 * KS; ++ks) {
-        const bf16x8 x = *reinterpret_cast<const bf16x8*>(A + ks * 64);
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(A + ((ks ^ hi) << 6));
         acc[0] = mma16(wreg[0][ks], x, acc[0]);
         acc[1] = mma16(wreg[1][ks], x, acc[1]);
       }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 x = *reinterpret_cast<const bf16x8*>(A + 4 * H + ks * 64);
-        const bf16x8 n0 = *reinterpret_cast<const bf16x8*>(Wn + ks * 64);
-        const bf16x8 n1 = *reinterpret_cast<const bf16x8*>(Wn + 16 * ROWB + ks * 64);
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(A + 4 * H + ((ks ^ hi) << 6));
+        const bf16x8 n0 = *reinterpret_cast<const bf16x8*>(Wn + ((ks ^ hi) << 6));
+        const bf16x8 n1 = *reinterpret_cast<const bf16x8*>(Wn + 16 * ROWB + ((ks ^ hi) << 6));
         acc[0] = mma16(n0, x, acc[0]);
         acc[1] = mma16(n1, x, acc[1]);
       }
@@ -259,9 +298,8 @@ __global__ __launch_bounds__(PersistGeo<H>::NTH) void enc_bwd_persist_kernel(Enc
     for (int nt = 0; nt < 2; ++nt) {
       float dh[4];
       if (first) {
-        const f32x4 inj = *reinterpret_cast<const f32x4*>(a.dhfin + (long)b * H + u0 + nt * 16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dh[i] = inj[i];
+        for (int i = 0; i < 4; ++i) dh[i] = inj[nt][i];
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) dh[i] = dhc[nt][i] + acc[nt][i];
@@ -277,29 +315,35 @@ __global__ __launch_bounds__(PersistGeo<H>::NTH) void enc_bwd_persist_kernel(Enc
         dnr[nt][i] = dn[nt][i] * r;
         dhc[nt][i] = d * z;
       }
-      if (live) {
+      {
         const long s = (long)(o + b) * 3 * H + u0 + nt * 16;
-        *reinterpret_cast<bf16x4*>(a.dGI + s) = to_bf16x4(dr[nt]);
-        *reinterpret_cast<bf16x4*>(a.dGI + s + H) = to_bf16x4(dzg[nt]);
-        *reinterpret_cast<bf16x4*>(a.dGI + s + 2 * H) = to_bf16x4(dn[nt]);
-        *reinterpret_cast<bf16x4*>(a.dGH + s) = to_bf16x4(dr[nt]);
-        *reinterpret_cast<bf16x4*>(a.dGH + s + H) = to_bf16x4(dzg[nt]);
-        *reinterpret_cast<bf16x4*>(a.dGH + s + 2 * H) = to_bf16x4(dnr[nt]);
+        store_b64(r_dGI, live, s, to_bf16x4(dr[nt]));
+        store_b64(r_dGI, live, s + H, to_bf16x4(dzg[nt]));
+        store_b64(r_dGI, live, s + 2 * H, to_bf16x4(dn[nt]));
+        store_b64(r_dGH, live, s, to_bf16x4(dr[nt]));
+        store_b64(r_dGH, live, s + H, to_bf16x4(dzg[nt]));
+        store_b64(r_dGH, live, s + 2 * H, to_bf16x4(dnr[nt]));
       }
     }
-    __syncthreads();   // every wave has finished reading dGH_{t+1}
+    lds_barrier();   // every wave has finished reading dGH_{t+1}
     {
       char* An = sA + lr * ROWA;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         const int u = u0 + nt * 16;
-        *reinterpret_cast<bf16x4*>(An + u * 2) = to_bf16x4(dr[nt]);
-        *reinterpret_cast<bf16x4*>(An + (H + u) * 2) = to_bf16x4(dzg[nt]);
-        *reinterpret_cast<bf16x4*>(An + (2 * H + u) * 2) = to_bf16x4(dnr[nt]);
+        const int sw = (((u >> 3) ^ lr) << 4) + (u & 7) * 2;   // H * 2 bytes = 32 chunks: the gate offset keeps the XOR group
+        *reinterpret_cast<bf16x4*>(An + sw) = to_bf16x4(dr[nt]);
+        *reinterpret_cast<bf16x4*>(An + H * 2 + sw) = to_bf16x4(dzg[nt]);
+        *reinterpret_cast<bf16x4*>(An + 2 * H * 2 + sw) = to_bf16x4(dnr[nt]);
       }
     }
-    sv = svn;
-    __syncthreads();
+    lds_barrier();
+  };
+  Saved sv2;
+  for (int t = Tb - 1; t >= 0; t -= 3) {
+    step(t, sv, sv2);
+    if (t - 1 >= 0) step(t - 1, sv1, sv);
+    if (t - 2 >= 0) step(t - 2, sv2, sv1);
   }
 }
 
