@@ -48,7 +48,7 @@ template <int H> struct PersistGeo {
   static constexpr int ROWB_3H = 3 * H * 2;      // the same layout (XOR inside each aligned group of 16 chunks)
   static constexpr int WN_BYTES = H * ROWB_H;    // n-gate weight rows kept in LDS
   static constexpr int FWD_SMEM = WN_BYTES + 2 * PR * ROWB_H;
-  static constexpr int BWD_SMEM = H * ROWB_X + PR * ROWB_3H;
+  static constexpr int BWD_SMEM = H * ROWB_X + PR * ROWB_3H + PR * ROWB_X;   // + the dn tile (the n gate of dGI)
 };
 
 // first element of the lane-major slot of (step t, block at row0): packed offset of the step + 16 rows of padding per
@@ -209,6 +209,7 @@ __global__ __launch_bounds__(PersistGeo<H>::NTH) void enc_bwd_persist_kernel(Enc
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sWn = smem;                 // [H][ROWB]: W_hh^T[j][2H + k]
   char* sA = smem + H * ROWB;       // [PR][ROWA]: dGH_{t+1} of the block's sequences (bf16)
+  char* sDn = sA + PR * ROWA;       // [PR][ROWB]: dn_t, the one gate in which dGI differs from dGH
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
@@ -250,9 +251,8 @@ __global__ __launch_bounds__(PersistGeo<H>::NTH) void enc_bwd_persist_kernel(Enc
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int i = 0; i < 4; ++i) dhc[nt][i] = 0.0f;
-  Saved sv, sv1;   // saved activations of steps t and t-1: fetched two steps ahead (an HBM miss outlasts a step)
+  Saved sv, sv1;   // saved activations of step t and (in flight) of step t-1
   if (Tb > 0) load_saved(Tb - 1, sv);
-  if (Tb > 0) load_saved(Tb - 2, sv1);
   const __amdgpu_buffer_rsrc_t r_dGI = pg_make_rsrc(a.dGI), r_dGH = pg_make_rsrc(a.dGH);
   // gradient injected at this lane's sequence's last step: loaded once.  A load inside the step loop - even a
   // conditional one - makes hipcc wait for vmcnt(0) at the join, i.e. for the previous step's store acknowledgements and
@@ -263,11 +263,11 @@ __global__ __launch_bounds__(PersistGeo<H>::NTH) void enc_bwd_persist_kernel(Enc
     inj[nt] = b < a.B ? *reinterpret_cast<const f32x4*>(a.dhfin + (long)b * H + u0 + nt * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
 
-  // one step; `sv` holds the saved activations of step t (requested two steps ago), `svn` receives those of step t-2.
-  // The three register sets rotate by NAME (the loop below is unrolled by three): a register copy of a set still in flight
+  // one step; `sv` holds the saved activations of step t (requested a step ago), `svn` receives those of step t-1.
+  // The two register sets swap by NAME (the loop below is unrolled by two): a register copy of a set still in flight
   // would make hipcc wait for it - and, vmcnt being one in-order counter, for every store issued before it.
   auto step = [&](int t, const Saved& sv, Saved& svn) __attribute__((always_inline)) {
-    load_saved(t - 2, svn);   // t - 2 < 0 reads step 0's first row, unused
+    load_saved(t - 1, svn);   // t - 1 < 0 reads step 0's first row, unused
     f32x4 acc[2];
     acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
     acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -315,15 +315,6 @@ __global__ __launch_bounds__(PersistGeo<H>::NTH) void enc_bwd_persist_kernel(Enc
         dnr[nt][i] = dn[nt][i] * r;
         dhc[nt][i] = d * z;
       }
-      {
-        const long s = (long)(o + b) * 3 * H + u0 + nt * 16;
-        store_b64(r_dGI, live, s, to_bf16x4(dr[nt]));
-        store_b64(r_dGI, live, s + H, to_bf16x4(dzg[nt]));
-        store_b64(r_dGI, live, s + 2 * H, to_bf16x4(dn[nt]));
-        store_b64(r_dGH, live, s, to_bf16x4(dr[nt]));
-        store_b64(r_dGH, live, s + H, to_bf16x4(dzg[nt]));
-        store_b64(r_dGH, live, s + 2 * H, to_bf16x4(dnr[nt]));
-      }
     }
     lds_barrier();   // every wave has finished reading dGH_{t+1}
     {
@@ -335,15 +326,32 @@ __global__ __launch_bounds__(PersistGeo<H>::NTH) void enc_bwd_persist_kernel(Enc
         *reinterpret_cast<bf16x4*>(An + sw) = to_bf16x4(dr[nt]);
         *reinterpret_cast<bf16x4*>(An + H * 2 + sw) = to_bf16x4(dzg[nt]);
         *reinterpret_cast<bf16x4*>(An + 2 * H * 2 + sw) = to_bf16x4(dnr[nt]);
+        *reinterpret_cast<bf16x4*>(sDn + lr * ROWB + sw) = to_bf16x4(dn[nt]);
       }
     }
     lds_barrier();
+    // dGH_t and dGI_t go to memory from the LDS tile, row-major and coalesced: 16-byte chunk c of row r sits at position
+    // c ^ (r & 15) of its 16-chunk group.  (As 12 per-lane stores of 16 rows x 32 bytes they cost the step more than its
+    // arithmetic.)  The tile is next written after the next step's first barrier, which every wave reaches after these reads.
+    {
+      const unsigned oob = 0x80000000u;
+      constexpr int CPR = 3 * H / 8;               // 16-byte chunks per row of a [., 3H] bf16 array
+#pragma unroll
+      for (int k = 0; k < PR * CPR / G::NTH; ++k) {
+        const int idx = tid + k * G::NTH;
+        const int row = idx / CPR, c = idx % CPR;
+        const bool ok = row0 + row < Bt;
+        const unsigned goff = ok ? (unsigned)(((long)(o + row0 + row) * 3 * H) * 2 + c * 16) : oob;
+        const u32x4 vh = *reinterpret_cast<const u32x4*>(sA + row * ROWA + ((c ^ (row & 15)) << 4));
+        __builtin_amdgcn_raw_buffer_store_b128(vh, r_dGH, (int)goff, 0, 0);
+        const u32x4 vi = c < 2 * H / 8 ? vh : *reinterpret_cast<const u32x4*>(sDn + row * ROWB + (((c - 2 * H / 8) ^ (row & 15)) << 4));
+        __builtin_amdgcn_raw_buffer_store_b128(vi, r_dGI, (int)goff, 0, 0);
+      }
+    }
   };
-  Saved sv2;
-  for (int t = Tb - 1; t >= 0; t -= 3) {
-    step(t, sv, sv2);
+  for (int t = Tb - 1; t >= 0; t -= 2) {
+    step(t, sv, sv1);
     if (t - 1 >= 0) step(t - 1, sv1, sv);
-    if (t - 2 >= 0) step(t - 2, sv2, sv1);
   }
 }
 
