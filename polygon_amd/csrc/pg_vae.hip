@@ -669,8 +669,25 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
     PG_TRY(launch_gru_bwd_diag<T>(dg, st));
   }
   prof_end(1, pslot, st, sd.T + L, pflop);
-  // The dz path first (it is what the encoder BPTT waits for); the large weight-gradient GEMMs last - on the side stream
-  // when deferral is on (they then run beside pg_encoder_bwd).
+  // The five large weight-gradient GEMMs need nothing but the recurrence's outputs.  With deferral on they go to the side
+  // stream right here (forked behind the recurrence) and run beside the dz chain below - a string of small kernels that
+  // leaves the GPU idle - and beside pg_encoder_bwd; with deferral off they run here, in stream order.
+  hipStream_t sg = st;
+  PG_TRY(defer_fork(st, &sg));
+  for (int l = L - 1; l >= 0; --l) {
+    T* dGI = at<T>(ws, w.b_dGI_l[l]);
+    T* dGH = at<T>(ws, w.b_dGH_l[l]);
+    // weight gradients of the layer, batched over all packed rows; the bias gradients (column sums of dGH / dGI) ride along
+    PG_TRY(launch_gemm_tn<T>(dGH, 3 * Hd, at<T>(ws, w.d_sv[l][4]), Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_whh[l], Hd, 1.0f,
+                             nullptr, sg, grads + po.dec_bhh[l]));
+    if (l > 0) {
+      const T* X = drop ? at<T>(ws, w.d_hdrop[l - 1]) : at<T>(ws, w.d_hseq[l - 1]);
+      PG_TRY(launch_gemm_tn<T>(dGI, 3 * Hd, X, Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_wih[l], Hd, 1.0f, nullptr, sg,
+                               grads + po.dec_bih[l]));
+    }
+  }
+  PG_TRY(defer_done(sg, st));
+  // ---- the dz path (what the encoder BPTT waits for) and the small weight gradients
   {
     T* dGI = at<T>(ws, w.b_dGI_l[0]);
     // layer 0 input = [x_emb[token] ; z]: token half through the gather table, z half per sequence
@@ -695,21 +712,6 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
     e.C32 = dz; e.ldc = Dz;
     PG_TRY(launch_gemm_nt<T>(dzp_op, 3 * Hd, at<T>(shadow, so.wih0zT), 3 * Hd, B, Dz, 3 * Hd, e, st));
   }
-  hipStream_t sg = st;
-  PG_TRY(defer_fork(st, &sg));
-  for (int l = L - 1; l >= 0; --l) {
-    T* dGI = at<T>(ws, w.b_dGI_l[l]);
-    T* dGH = at<T>(ws, w.b_dGH_l[l]);
-    // weight gradients of the layer, batched over all packed rows; the bias gradients (column sums of dGH / dGI) ride along
-    PG_TRY(launch_gemm_tn<T>(dGH, 3 * Hd, at<T>(ws, w.d_sv[l][4]), Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_whh[l], Hd, 1.0f,
-                             nullptr, sg, grads + po.dec_bhh[l]));
-    if (l > 0) {
-      const T* X = drop ? at<T>(ws, w.d_hdrop[l - 1]) : at<T>(ws, w.d_hseq[l - 1]);
-      PG_TRY(launch_gemm_tn<T>(dGI, 3 * Hd, X, Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_wih[l], Hd, 1.0f, nullptr, sg,
-                               grads + po.dec_bih[l]));
-    }
-  }
-  PG_TRY(defer_done(sg, st));
   // decoder_lat: h0 = W z + b feeds every layer
   T* dh0_op = at<T>(ws, w.b_dh0_op);
   if (!persist) PG_TRY(convert_to<T>(dh0, dh0_op, (long)B * Hd, st));
