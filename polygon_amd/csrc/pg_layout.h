@@ -157,7 +157,8 @@ static inline TrainWs train_ws_layout(const pg_dims* d, int dtype, long B, long 
     w.d_carry[l] = take(B * Hd * 4);
     w.d_hseq[l] = take(Nd * Hd * es);
     w.d_hdrop[l] = take(Nd * Hd * es);
-    for (int i = 0; i < 5; ++i) w.d_sv[l][i] = take(Nd * Hd * es);
+    for (int i = 0; i < 4; ++i) w.d_sv[l][i] = take((Nd + 16 * 11 * 512 + 16) * Hd * es);   // lane-order slots (PG_SV_LANE_PAD_ROWS, pg_persist.h)
+    w.d_sv[l][4] = take(Nd * Hd * es);
   }
   w.d_gi = take(Nd * 3 * Hd * 4);
   w.d_logits = take(Nd * Vp * 4); w.d_dlogits = take(Nd * Vp * es);

@@ -62,6 +62,7 @@ struct DecFwdPersist {
   bf16_t* hdrop[PG_MAX_LAYERS] = {};          // packed [N, H]: dropout-masked outputs (null: no dropout / top layer)
   float* carry[PG_MAX_LAYERS] = {};           // [B, H] fp32 state
   bf16_t* sv[PG_MAX_LAYERS][5] = {};          // packed [N, H] r, z, n, hn, hprev (null: inference)
+  int sv_lane = 0;                            // sv[l][0..3] in lane order (sv_tile_slot) instead of packed rows: see pg_persist_dec.hip
   float p_drop = 0.0f;
   uint64_t seed = 0;
   int b_mul = 1, b_add = 0;
@@ -95,6 +96,15 @@ __device__ __forceinline__ bool persist_map(int bid, int NG, int NCU, int& g, in
   return true;
 }
 
+// Lane-order storage of the saved gate activations r, z, n, hn (read back by the BPTT kernel only, lane for lane): the
+// 16-row tile j of group g at step t owns slot sv_tile_slot(...) of 16 x H elements, laid out [slice 8][wave 4][lane 64][4].
+// Tiles of step t start at floor(off[t] / 16) + (NG + 1) * t, which leaves room for every group's partial last tile:
+// at most N / 16 + (NG + 1) * T + 1 slots.
+__device__ __forceinline__ long sv_tile_slot(int off_t, int t, int NG, int j, int g) {
+  return (long)(off_t >> 4) + (long)(NG + 1) * t + (long)j * NG + g;
+}
+constexpr long PG_SV_LANE_PAD_ROWS = 16L * (10 + 1) * 512 + 16;   // rows beyond the packed count (NG <= 10, T <= 512)
+
 // Decoder stack, backward (BPTT): the same grouping, workgroup (layer l, slice c) keeps the rows of W_hh_l^T and
 // W_ih_{l+1}^T that produce dh of its 64 units.  It consumes dGH_{l,t+1} (own layer) and dGI_{l+1,t} (layer above) as
 // published by the other workgroups and publishes dGI_{l,t} / dGH_{l,t}; see pg_persist_bwd.hip.
@@ -108,6 +118,7 @@ struct DecBwdPersist {
   bf16_t* dGH[PG_MAX_LAYERS] = {};            // packed [N, 3H] (published)
   float* carry[PG_MAX_LAYERS] = {};           // [B, H] z.dh carried to the previous step
   float* dh0[PG_MAX_LAYERS] = {};             // [B, H] per-layer gradient of h0 (summed by the launcher)
+  int sv_lane = 0;                            // sv[l][0..3] are in lane order, as the forward kernel wrote them
   float p_drop = 0.0f;
   uint64_t seed = 0;
   int b_mul = 1, b_add = 0;

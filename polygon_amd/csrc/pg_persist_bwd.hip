@@ -233,10 +233,12 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
       if (t >= 0 && !(a.dbg & 4)) {
         const long sidx = (long)(o + bs) * H + u0;
         if constexpr (TOP) dtop = *reinterpret_cast<const f32x4*>(a.dout + sidx);
-        svr = *reinterpret_cast<const bf16x4*>(a.sv[l][0] + sidx);
-        svz = *reinterpret_cast<const bf16x4*>(a.sv[l][1] + sidx);
-        svn = *reinterpret_cast<const bf16x4*>(a.sv[l][2] + sidx);
-        svhn = *reinterpret_cast<const bf16x4*>(a.sv[l][3] + sidx);
+        // lane order, as the forward kernel wrote them (pg_persist.h, sv_tile_slot)
+        const long sl = a.sv_lane ? ((sv_tile_slot(o, t, NG, j, g) * NCU + c) * 256 + wave * 64 + lane) * 4 : sidx;
+        svr = *reinterpret_cast<const bf16x4*>(a.sv[l][0] + sl);
+        svz = *reinterpret_cast<const bf16x4*>(a.sv[l][1] + sl);
+        svn = *reinterpret_cast<const bf16x4*>(a.sv[l][2] + sl);
+        svhn = *reinterpret_cast<const bf16x4*>(a.sv[l][3] + sl);
         svhp = *reinterpret_cast<const bf16x4*>(a.sv[l][4] + sidx);
       }
       f32x4 ah[2], au[2];

@@ -376,10 +376,16 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
           store_pub_b64<AUXL>(r_hdrop, o2, to_bf16x4(hd));
         }
         if (has_sv) {
-          store_pub_b64<0>(pg_make_rsrc(a.sv[l][0]), o2, to_bf16x4(r));
-          store_pub_b64<0>(pg_make_rsrc(a.sv[l][1]), o2, to_bf16x4(z));
-          store_pub_b64<0>(pg_make_rsrc(a.sv[l][2]), o2, to_bf16x4(n));
-          store_pub_b64<0>(pg_make_rsrc(a.sv[l][3]), o2, to_bf16x4(hn));
+          // r, z, n, hn go back to the BPTT kernel lane for lane: stored in lane order they are 512 contiguous bytes per
+          // wave instruction; as packed rows they are 16 rows x 32 bytes, which the address path serialises into 16
+          // cache-line accesses (~35 cycles of the CU per instruction).  h_prev stays row-major: it is a GEMM operand.
+          unsigned o_sv = o2;
+          if (a.sv_lane)   // kernel-uniform
+            o_sv = st ? (unsigned)((((sv_tile_slot(o, t, NG, j, g) * NCU + c) * 256 + wave * 64 + lane) * 4) * 2) : oob;
+          store_pub_b64<0>(pg_make_rsrc(a.sv[l][0]), o_sv, to_bf16x4(r));
+          store_pub_b64<0>(pg_make_rsrc(a.sv[l][1]), o_sv, to_bf16x4(z));
+          store_pub_b64<0>(pg_make_rsrc(a.sv[l][2]), o_sv, to_bf16x4(n));
+          store_pub_b64<0>(pg_make_rsrc(a.sv[l][3]), o_sv, to_bf16x4(hn));
           store_pub_b64<0>(pg_make_rsrc(a.sv[l][4]), o2, to_bf16x4(hp));
         }
       }
