@@ -98,8 +98,12 @@ template <int H> struct DecGeo {
   static constexpr int TILE_BYTES = ACT_BYTES + CARRY_BYTES;
   static constexpr int TILE0_BYTES = ACT_BYTES / 2 + CARRY_BYTES + 2 * GATE_BYTES;
   static constexpr int TOK_BYTES = 128 * 4;           // layer 0: the step's tokens of this group (<= 128 sequences)
-  static constexpr int SMEM = WIN_BYTES + 2 * TILE_BYTES + 16;   // + the broadcast word of the poll result
-  static_assert(2 * TILE0_BYTES + TOK_BYTES + 16 <= SMEM, "layer-0 layout must fit the common allocation");
+  // output staging: the bf16 rows a tile publishes (h, dropout(h)) or saves row-major (h_prev), [2 buffers][3 arrays][16 rows]
+  // of 64 units, rows padded to 144 bytes; written per lane, read back as 128-byte row segments for coalesced stores
+  static constexpr int STG_ROW = 144, STG_ARR = 16 * STG_ROW, STG_BUF = 3 * STG_ARR;
+  static constexpr int STG_OFF = WIN_BYTES + 2 * TILE_BYTES;
+  static constexpr int SMEM = STG_OFF + 2 * STG_BUF + 16;        // + the broadcast word of the poll result
+  static_assert(2 * TILE0_BYTES + TOK_BYTES <= STG_OFF, "layer-0 layout must fit in front of the staging block");
 };
 
 template <int H, bool L0, int AUXL>
@@ -175,7 +179,9 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   const bool has_drop = hdrop != nullptr, has_sv = a.sv[l][0] != nullptr;     // kernel-uniform
-  const int NS = 2 + (has_drop ? 1 : 0) + (has_sv ? 5 : 0);                     // store instructions per wave and tile
+  const int narr = 1 + (has_drop ? 1 : 0) + (has_sv ? 1 : 0);                   // row-major bf16 outputs: h, dropout(h), h_prev
+  const int NS = 1 + (narr > 2 ? 2 : 1) + (has_sv ? 4 : 0);                     // store instructions per wave and tile
+  char* sStage = smem + G::STG_OFF;
   const __amdgpu_buffer_rsrc_t r_carry = pg_make_rsrc(carry);
   // vector memory operations of a wave complete in issue order and loads and stores share ONE counter, so a wait is
   // written as "all but the youngest n": n = the stores issued after the DMA that must have landed
@@ -183,6 +189,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
     switch (n) {
       case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
       case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
       case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
       case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
       case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
@@ -353,8 +360,27 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
         n[e] = tanhf_(g3[2][e] + acc[3][e] + r[e] * hn[e]);
         h[e] = (1.0f - z[e]) * n[e] + z[e] * hp[e];
       }
+      // The rows this tile publishes or saves row-major go to memory through a small LDS staging block: a lane holds 4
+      // units of one row, so a direct store is 16 rows x 32 bytes per wave instruction - 16 cache-line accesses that the
+      // address path serialises (~35 CU cycles each) - while 128-byte row segments read back from LDS are 8 lines per
+      // instruction and a third as many instructions.  Two buffers: the block is rewritten two barriers later.
+      {
+        char* S = sStage + (j & 1) * G::STG_BUF + lr * G::STG_ROW + (wave * 16 + lq * 4) * 2;
+        *reinterpret_cast<bf16x4*>(S) = to_bf16x4(h);
+        int k = 1;
+        if (has_drop) {
+          float hd[4], m[4];
+          dropout_scale4(a.seed, l, t, b * a.b_mul + a.b_add, u0 >> 2, a.p_drop, inv_keep, m);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hd[e] = h[e] * m[e];
+          *reinterpret_cast<bf16x4*>(S + k * G::STG_ARR) = to_bf16x4(hd);
+          ++k;
+        }
+        if (has_sv) *reinterpret_cast<bf16x4*>(S + k * G::STG_ARR) = to_bf16x4(hp);
+      }
       // tile j+1 must have landed (this wave's DMAs; the barrier extends it to the others): everything older than the
       // previous tile's stores.  The barrier also says that every wave is done reading tile j.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (!(a.dbg & 1)) wait_all_but(j > 0 ? NS : 0);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -367,18 +393,24 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
         const unsigned o2 = st ? (unsigned)(s * 2) : oob;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{h[0], h[1], h[2], h[3]}), r_carry,
                                                (int)(st ? (unsigned)(((long)b * H + u0) * 4) : oob), 0, 0);
-        store_pub_b64<AUXL>(r_hseq, o2, to_bf16x4(h));
-        if (has_drop) {
-          float hd[4], m[4];
-          dropout_scale4(a.seed, l, t, b * a.b_mul + a.b_add, u0 >> 2, a.p_drop, inv_keep, m);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) hd[e] = h[e] * m[e];
-          store_pub_b64<AUXL>(r_hdrop, o2, to_bf16x4(hd));
+        // cooperative row-segment stores: 128 lanes per array (16 rows x 8 lanes of 16 bytes); waves 0-1 take the first
+        // array of a round, waves 2-3 the second; every wave issues one store per round (out of range when it has none)
+        const char* SB = sStage + (j & 1) * G::STG_BUF;
+        const int row = (lane >> 3) + ((wave & 1) << 3), seg = lane & 7;
+        const int brow = g + NG * (16 * j + row);
+        const bool rlive = brow < Bt && !((a.dbg & 4) && h[0] != 12345.678f);
+        const unsigned orow = (unsigned)((((long)(o + brow) * H + c * 64) * 2) + seg * 16);
+        for (int rd = 0; rd < (narr > 2 ? 2 : 1); ++rd) {   // kernel-uniform trip count
+          const int arr = 2 * rd + (wave >> 1);                // wave-uniform
+          const u32x4 v = *reinterpret_cast<const u32x4*>(SB + (arr < 3 ? arr : 0) * G::STG_ARR + row * G::STG_ROW + seg * 16);
+          const unsigned off = (arr < narr && rlive) ? orow : oob;
+          if (arr == 0) __builtin_amdgcn_raw_buffer_store_b128(v, r_hseq, (int)off, 0, AUXL);
+          else if (arr == 1 && has_drop) __builtin_amdgcn_raw_buffer_store_b128(v, r_hdrop, (int)off, 0, AUXL);
+          else __builtin_amdgcn_raw_buffer_store_b128(v, pg_make_rsrc(a.sv[l][4] ? a.sv[l][4] : hseq), (int)off, 0, 0);
         }
         if (has_sv) {
           // r, z, n, hn go back to the BPTT kernel lane for lane: stored in lane order they are 512 contiguous bytes per
-          // wave instruction; as packed rows they are 16 rows x 32 bytes, which the address path serialises into 16
-          // cache-line accesses (~35 cycles of the CU per instruction).  h_prev stays row-major: it is a GEMM operand.
+          // wave instruction (pg_persist.h, sv_tile_slot); packed rows when the BPTT of this step is not the persistent kernel
           unsigned o_sv = o2;
           if (a.sv_lane)   // kernel-uniform
             o_sv = st ? (unsigned)((((sv_tile_slot(o, t, NG, j, g) * NCU + c) * 256 + wave * 64 + lane) * 4) * 2) : oob;
@@ -386,7 +418,6 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
           store_pub_b64<0>(pg_make_rsrc(a.sv[l][1]), o_sv, to_bf16x4(z));
           store_pub_b64<0>(pg_make_rsrc(a.sv[l][2]), o_sv, to_bf16x4(n));
           store_pub_b64<0>(pg_make_rsrc(a.sv[l][3]), o_sv, to_bf16x4(hn));
-          store_pub_b64<0>(pg_make_rsrc(a.sv[l][4]), o2, to_bf16x4(hp));
         }
       }
       if (j == 0) PG_STAMP(4);
