@@ -95,7 +95,8 @@ template <int H, bool TOP> struct BwdGeo {
   static constexpr int WN_BYTES = TOP ? 0 : 64 * ROWW;
   static constexpr int NSLOT = TOP ? 8 : 5;
   static constexpr int D = NSLOT - 2;            // parts in flight behind the one being consumed
-  static constexpr int SMEM = WN_BYTES + NSLOT * PART_BYTES + 16;
+  static constexpr int STG_BYTES = 4 * 16 * 128;  // staging of a tile's gate gradients: dr, dz, dn.r, dn x 16 rows x 64 units (bf16)
+  static constexpr int SMEM = WN_BYTES + NSLOT * PART_BYTES + STG_BYTES + 16;
 };
 
 template <int H, bool TOP, int AUXL>
@@ -106,7 +107,8 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
   static_assert(D <= 6, "wait_parts covers at most 6 parts in flight");
   char* sWn = smem;
   char* sR = smem + G::WN_BYTES;
-  volatile unsigned* sFlag = reinterpret_cast<volatile unsigned*>(smem + G::WN_BYTES + NSLOT * PART_BYTES);
+  char* sStage = smem + G::WN_BYTES + NSLOT * PART_BYTES;
+  volatile unsigned* sFlag = reinterpret_cast<volatile unsigned*>(sStage + G::STG_BYTES);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4, hi = lr >> 2;
@@ -367,15 +369,36 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
           dhz[e] = dh[e] * z;
         }
         *reinterpret_cast<f32x4*>(carry + (long)b * H + u0) = f32x4{dhz[0], dhz[1], dhz[2], dhz[3]};
-        const unsigned og = (unsigned)(((long)b * 3 * H + u0) * 2);
-        const bf16x4 vr = to_bf16x4(dr), vz = to_bf16x4(dz);
-        store_pub_b64<AUXL>(r_dGH, og, vr);
-        store_pub_b64<AUXL>(r_dGH, og + H * 2, vz);
-        store_pub_b64<AUXL>(r_dGH, og + 2 * H * 2, to_bf16x4(dnr));
-        store_pub_b64<AUXL>(r_dGI, og, vr);
-        store_pub_b64<AUXL>(r_dGI, og + H * 2, vz);
-        store_pub_b64<AUXL>(r_dGI, og + 2 * H * 2, to_bf16x4(dn));
+        // The published gate gradients leave through LDS: a lane holds 4 units of one row, so direct stores are 16 rows
+        // x 32 bytes per wave instruction (16 cache-line accesses, ~35 CU cycles each, 6 of them per tile); staged, they
+        // go out as 128-byte row segments.  Tile [gate][row][64 units], 16-byte chunk q of row r at position q ^ (r & 7).
+        char* S = sStage + lr * 128 + (((wave * 2 + (lq >> 1)) ^ (lr & 7)) << 4) + (lq & 1) * 8;
+        *reinterpret_cast<bf16x4*>(S) = to_bf16x4(dr);
+        *reinterpret_cast<bf16x4*>(S + 2048) = to_bf16x4(dz);
+        *reinterpret_cast<bf16x4*>(S + 4096) = to_bf16x4(dnr);
+        *reinterpret_cast<bf16x4*>(S + 6144) = to_bf16x4(dn);
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (!(a.dbg & 4)) {
+        // 2 arrays x 3 gates x 16 rows x 8 segments = 768 segment stores, 3 per thread; array and gate are wave-uniform
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int wq = k * 4 + wave;                       // 0..11
+          const int arr = wq / 6, gate = (wq % 6) >> 1;
+          const int row = ((wq & 1) << 3) + (lane >> 3), seg = lane & 7;
+          const int tile = gate < 2 ? gate : (arr ? 3 : 2);
+          const u32x4 v = *reinterpret_cast<const u32x4*>(sStage + tile * 2048 + row * 128 + ((seg ^ (row & 7)) << 4));
+          const int brow = g + NG * (16 * j + row);
+          const unsigned off = brow < Bt ? (unsigned)((((long)brow * 3 * H + gate * H + c * 64) * 2) + seg * 16) : 0x80000000u;
+          if (arr == 0) __builtin_amdgcn_raw_buffer_store_b128(v, r_dGH, (int)off, 0, AUXL);
+          else __builtin_amdgcn_raw_buffer_store_b128(v, r_dGI, (int)off, 0, AUXL);
+        }
+      }
+      // the staging tile is rewritten by the next tile's epilogue, behind that tile's part barriers; a tile without
+      // parts (top layer, first step) needs one of its own
+      if (Pt == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
     }
     PG_STAMP(5);
     // ---- publish step t of this unit slice (also: every wave is done with the ring before the next step refills it)
