@@ -541,7 +541,8 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
     static_assert(FCfg::SMEM_BYTES >= 128 * 65 * 4, "fc_ce kernel: LDS too small for the logits tile");
     PG_LAUNCH_BIG_SMEM(fc_ce_kernel<FCfg>, dim3(cdiv(Nd, FCfg::BM)), dim3(FCfg::NTHREADS), FCfg::SMEM_BYTES, st,
                        at<T>(ws, w.d_hseq[L - 1]), Nd, Hd, at<T>(shadow, so.fc_w), at<float>(shadow, so.fc_b), d->V, Vp,
-                       at<int>(ws, w.dec_tgt), d->pad, at<float>(ws, w.d_logits), save ? at<T>(ws, w.d_dlogits) : (T*)nullptr, scal);
+                       at<int>(ws, w.dec_tgt), d->pad, logits_packed ? at<float>(ws, w.d_logits) : (float*)nullptr,   // logits only when the caller takes them
+                       save ? at<T>(ws, w.d_dlogits) : (T*)nullptr, scal);
     PG_CHECK_LAUNCH();
   } else {
     {  // vocab projection
@@ -595,8 +596,7 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   const float* s_ce = scal + SC_GS_CE;
   T* dlog = at<T>(ws, w.d_dlogits);
   const T* top = at<T>(ws, w.d_hseq[L - 1]);
-  // decoder_fc
-  PG_TRY(launch_gemm_tn<T>(dlog, Vp, top, Hd, V, Hd, (int)Nd, grads + po.fc_w, Hd, 1.0f, s_ce, st, grads + po.fc_b));
+  // (decoder_fc's weight gradient is enqueued with the other weight gradients, behind the recurrence)
   float* dout = at<float>(ws, w.b_dout);
   {
     GemmEpi<T> e;
@@ -680,6 +680,7 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   // leaves the GPU idle - and beside pg_encoder_bwd; with deferral off they run here, in stream order.
   hipStream_t sg = st;
   PG_TRY(defer_fork(st, &sg));
+  PG_TRY(launch_gemm_tn<T>(dlog, Vp, top, Hd, V, Hd, (int)Nd, grads + po.fc_w, Hd, 1.0f, s_ce, sg, grads + po.fc_b));   // decoder_fc
   for (int l = L - 1; l >= 0; --l) {
     T* dGI = at<T>(ws, w.b_dGI_l[l]);
     T* dGH = at<T>(ws, w.b_dGH_l[l]);
