@@ -180,7 +180,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
   typedef __attribute__((address_space(3))) void* lptr_t;
   const bool has_drop = hdrop != nullptr, has_sv = a.sv[l][0] != nullptr;     // kernel-uniform
   const int narr = 1 + (has_drop ? 1 : 0) + (has_sv ? 1 : 0);                   // row-major bf16 outputs: h, dropout(h), h_prev
-  const int NS = 1 + (narr > 2 ? 2 : 1) + (has_sv ? 4 : 0);                     // store instructions per wave and tile
+  const int NS = 1 + (narr > 2 ? 2 : 1) + (has_sv ? (a.sv_lane ? 2 : 4) : 0);   // store instructions per wave and tile
   char* sStage = smem + G::STG_OFF;
   const __amdgpu_buffer_rsrc_t r_carry = pg_make_rsrc(carry);
   // vector memory operations of a wave complete in issue order and loads and stores share ONE counter, so a wait is
@@ -189,6 +189,8 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
     switch (n) {
       case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
       case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
       case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
       case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
       case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
@@ -411,13 +413,19 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
         if (has_sv) {
           // r, z, n, hn go back to the BPTT kernel lane for lane: stored in lane order they are 512 contiguous bytes per
           // wave instruction (pg_persist.h, sv_tile_slot); packed rows when the BPTT of this step is not the persistent kernel
-          unsigned o_sv = o2;
-          if (a.sv_lane)   // kernel-uniform
-            o_sv = st ? (unsigned)((((sv_tile_slot(o, t, NG, j, g) * NCU + c) * 256 + wave * 64 + lane) * 4) * 2) : oob;
-          store_pub_b64<0>(pg_make_rsrc(a.sv[l][0]), o_sv, to_bf16x4(r));
-          store_pub_b64<0>(pg_make_rsrc(a.sv[l][1]), o_sv, to_bf16x4(z));
-          store_pub_b64<0>(pg_make_rsrc(a.sv[l][2]), o_sv, to_bf16x4(n));
-          store_pub_b64<0>(pg_make_rsrc(a.sv[l][3]), o_sv, to_bf16x4(hn));
+          if (a.sv_lane) {   // kernel-uniform: (r, z) pairs in sv[l][0..1], (n, hn) pairs in sv[l][2..3], 16 bytes per lane
+            const unsigned o16 = st ? (unsigned)(((sv_tile_slot(o, t, NG, j, g) * NCU + c) * 256 + wave * 64 + lane) * 16) : oob;
+            const bf16x4 vr = to_bf16x4(r), vz = to_bf16x4(z), vn = to_bf16x4(n), vh = to_bf16x4(hn);
+            const u32x2 ur = __builtin_bit_cast(u32x2, vr), uz = __builtin_bit_cast(u32x2, vz);
+            const u32x2 un = __builtin_bit_cast(u32x2, vn), uh = __builtin_bit_cast(u32x2, vh);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{ur[0], ur[1], uz[0], uz[1]}, pg_make_rsrc(a.sv[l][0]), (int)o16, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{un[0], un[1], uh[0], uh[1]}, pg_make_rsrc(a.sv[l][2]), (int)o16, 0, 0);
+          } else {
+            store_pub_b64<0>(pg_make_rsrc(a.sv[l][0]), o2, to_bf16x4(r));
+            store_pub_b64<0>(pg_make_rsrc(a.sv[l][1]), o2, to_bf16x4(z));
+            store_pub_b64<0>(pg_make_rsrc(a.sv[l][2]), o2, to_bf16x4(n));
+            store_pub_b64<0>(pg_make_rsrc(a.sv[l][3]), o2, to_bf16x4(hn));
+          }
         }
       }
       if (j == 0) PG_STAMP(4);

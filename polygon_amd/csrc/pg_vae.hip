@@ -244,6 +244,15 @@ static int defer_join(hipStream_t st, bool clear) {
 }
 extern "C" int pg_deferred_join(void* stream) { return defer_join((hipStream_t)stream, false); }
 
+// the lane-order form of the saved gate activations packs (r, z) into d_sv[l][0..1] and (n, hn) into d_sv[l][2..3]: the
+// two arrays of a pair must be one contiguous region (they are, by construction of train_ws_layout; checked, not assumed)
+static bool sv_pairs_adjacent(const TrainWs& w, int L) {
+  for (int l = 0; l < L; ++l) {
+    const size_t sz = w.d_sv[l][1] - w.d_sv[l][0];
+    if (w.d_sv[l][3] - w.d_sv[l][2] != sz || w.d_sv[l][2] - w.d_sv[l][1] != sz) return false;
+  }
+  return true;
+}
 static bool use_persistent_dec(int H, int L, int B) { return !(persist_off_mask() & 2) && dec_persist_supported(H, L, B); }
 static bool use_persistent_dec_bwd(int H, int L, int B) { return !(persist_off_mask() & 4) && dec_persist_supported(H, L, B); }
 
@@ -480,7 +489,7 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
         pa.carry[l] = at<float>(ws, w.d_carry[l]);
         if (save) for (int i = 0; i < 5; ++i) pa.sv[l][i] = at<T>(ws, w.d_sv[l][i]);
       }
-      pa.sv_lane = use_persistent_dec_bwd(Hd, L, B) ? 1 : 0;   // the BPTT of this step will be the persistent kernel too
+      pa.sv_lane = (use_persistent_dec_bwd(Hd, L, B) && sv_pairs_adjacent(w, L)) ? 1 : 0;   // the BPTT of this step will be the persistent kernel too
       pa.table = at<float>(shadow, so.tab_dec); pa.tok = at<int>(ws, w.dec_tok); pa.zproj = at<float>(ws, w.d_zproj);
       pa.h0_op = at<T>(ws, w.d_h0_op); pa.h0_32 = at<float>(ws, w.d_h0_32);
       pa.p_drop = p_drop; pa.seed = seed; pa.b_mul = b_mul; pa.b_add = b_add;
@@ -623,7 +632,7 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
       pa.p_drop = p_drop; pa.seed = seed; pa.b_mul = b_mul; pa.b_add = b_add;
       pa.sync = at<unsigned>(ws, w.sync);
       const int ps = prof_begin(1, st);
-      pa.sv_lane = use_persistent_dec(Hd, L, B) ? 1 : 0;   // the forward pass of this step was the persistent kernel
+      pa.sv_lane = (use_persistent_dec(Hd, L, B) && sv_pairs_adjacent(w, L)) ? 1 : 0;   // the forward pass of this step was the persistent kernel
       PG_TRY(launch_dec_bwd_persist(pa, sd, Hd, dh0, at<T>(ws, w.b_dh0_op), st));
       double pf = 0.0;   // algorithmic flop: dh = dGH_{t+1}.W_hh (+ dGI_{l+1,t}.W_ih_{l+1} below the top layer)
       for (int t = -1; t < sd.T; ++t) {
