@@ -50,7 +50,7 @@ sys.stdout.write("rank %%d ok\n" %% rank); sys.stdout.flush()   # one write: the
 def test_data_parallel_plumbing_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", GLOO_SOCKET_IFNAME="lo")   # gloo must not resolve the hostname
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29517", str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
