@@ -63,34 +63,6 @@ dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def test_two_rank_step_equals_single_process(tmp_path):
-    script = tmp_path / "worker.py"
-    script.write_text(WORKER % ROOT)
-    # Two plain interpreter processes with the rendezvous variables set by hand: torch.distributed.run pulls in the whole
-    # elastic-agent stack, whose first import on a fresh box (cold page cache) has taken more than two minutes.
-    # The ranks share ONE GPU here, so they use the per-step decoder kernels (bits 2 | 4): a group-persistent launch needs
-    # its whole grid resident, and two half-resident grids would wait for each other until their polling limits.  One
-    # process per GPU - the deployment model - never meets this; the persistent kernels under data-parallel keys are
-    # covered in-process below.
-    procs = []
-    for rank in range(2):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK=str(rank), LOCAL_RANK=str(rank),
-                   WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", PG_NO_PERSIST="6", GLOO_SOCKET_IFNAME="lo")   # gloo must not resolve the hostname
-        procs.append(subprocess.Popen([sys.executable, "-u", str(script)], env=env, stdout=subprocess.PIPE,
-                                      stderr=subprocess.PIPE, text=True))
-    outs = []
-    try:
-        for p in procs:
-            outs.append(p.communicate(timeout=90))
-    except subprocess.TimeoutExpired:
-        for p in procs:
-            p.kill()
-        raise AssertionError("two-rank worker timed out: %r" % ([p.communicate() for p in procs],))
-    for p, (so, se) in zip(procs, outs):
-        assert p.returncode == 0, so[-3000:] + se[-5000:]
-    assert sum(so.count("ok grad_rel_err") for so, _ in outs) == 4
-
-
 @pytest.mark.parametrize("dt", ["fp32", "bf16"])
 def test_shards_in_one_process_sum_to_whole_batch(dt):
     """The same equivalence without a second process: the two shards run one after the other through the PERSISTENT
@@ -125,3 +97,31 @@ def test_shards_in_one_process_sum_to_whole_batch(dt):
     assert err <= (1e-4 if dt == "fp32" else 2e-2), err
     assert abs(kl - kl0) <= 1e-4 * abs(kl0) + 1e-7
     assert abs(rec - rec0) <= (1e-4 if dt == "fp32" else 5e-3) * abs(rec0)
+
+
+def test_two_rank_step_equals_single_process(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    # Two plain interpreter processes with the rendezvous variables set by hand: torch.distributed.run pulls in the whole
+    # elastic-agent stack, whose first import on a fresh box (cold page cache) has taken more than two minutes.
+    # The ranks share ONE GPU here, so they use the per-step decoder kernels (bits 2 | 4): a group-persistent launch needs
+    # its whole grid resident, and two half-resident grids would wait for each other until their polling limits.  One
+    # process per GPU - the deployment model - never meets this; the persistent kernels under data-parallel keys are
+    # covered in-process below.
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK=str(rank), LOCAL_RANK=str(rank),
+                   WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", PG_NO_PERSIST="6", GLOO_SOCKET_IFNAME="lo")   # gloo must not resolve the hostname
+        procs.append(subprocess.Popen([sys.executable, "-u", str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=90))
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            p.kill()
+        raise AssertionError("two-rank worker timed out: %r" % ([p.communicate() for p in procs],))
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so[-3000:] + se[-5000:]
+    assert sum(so.count("ok grad_rel_err") for so, _ in outs) == 4
