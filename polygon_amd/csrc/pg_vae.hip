@@ -214,11 +214,9 @@ static int defer_fork(hipStream_t st, hipStream_t* side) {   // *side = stream f
   int dev = 0;
   PG_CHECK_HIP(hipGetDevice(&dev));
   if (!g_side) {
-    // lowest priority: the kernels of the caller's stream (the dz chain, the encoder BPTT) are on the step's critical path
-    // and get the CUs first; the deferred GEMMs fill what is left
-    int prio_lo = 0, prio_hi = 0;
-    PG_CHECK_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-    PG_CHECK_HIP(hipStreamCreateWithPriority(&g_side, hipStreamNonBlocking, prio_lo));
+    // default priority: a lowest-priority side stream was worth 15 us per step, but with two processes on one GPU (the
+    // two-rank test) the low-priority queue was intermittently never scheduled and the step hung
+    PG_CHECK_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
     PG_CHECK_HIP(hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming));
     PG_CHECK_HIP(hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming));
     g_defer_dev = dev;

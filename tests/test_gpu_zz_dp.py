@@ -122,11 +122,9 @@ def test_two_rank_step_equals_single_process(tmp_path):
     except subprocess.TimeoutExpired:
         for p in procs:
             p.kill()
-        # Seen on some boxes only, never twice in a row, with the per-step kernels as with the persistent ones: two
-        # processes sharing one GPU stall after the rendezvous.  That arrangement exists for this test alone (the
-        # library's model is one process per GPU; the shard arithmetic is asserted in-process above), so a stall is
-        # reported as a skip with the ranks' stacks, not as a failure of the build.
-        pytest.skip("two ranks on one GPU stalled: %r" % ([p.communicate() for p in procs],))
+        # (round 1: a lowest-priority side stream in one rank was intermittently never scheduled beside the other rank's
+        # queues - found through these stacks; the stream has default priority since)
+        raise AssertionError("two ranks on one GPU stalled: %r" % ([p.communicate() for p in procs],))
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, so[-3000:] + se[-5000:]
     assert sum(so.count("ok grad_rel_err") for so, _ in outs) == 4
