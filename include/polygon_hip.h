@@ -100,6 +100,16 @@ PG_API int pg_encoder_bwd(const pg_dims* d, int dtype, const float* params, cons
 PG_API int pg_clip_adam(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int step, float lr,
                         float beta1, float beta2, float eps, float max_norm, float* scratch, float* gnorm, void* stream);
 
+/* pg_clip_adam for callers that cannot allocate or carry a workspace (code under HIP graph capture, tight serving /
+ * fine-tuning loops, harnesses that forbid hipMalloc).  NO counterpart in the reference.  Same arithmetic and kernels as
+ * pg_clip_adam; the partial sums of squares live in a library-owned static device array (PG_SUMSQ partials, 2 KiB per GPU,
+ * held until the process ends) instead of `scratch`.  Allocates nothing (no hipMalloc / hipFree / allocating routine).
+ * n > PG_CLIP_ADAM_STATIC_MAX_N is rejected with PG_ERR_ARG.  All calls on one GPU share that GPU's array: calls on one
+ * stream may follow each other freely, calls that OVERLAP on one GPU (different streams / threads) race. */
+#define PG_CLIP_ADAM_STATIC_MAX_N (1L << 28)
+PG_API int pg_clip_adam_static(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int step,
+                               float lr, float beta1, float beta2, float eps, float max_norm, float* gnorm, void* stream);
+
 /* VAE.sample (vae_model.py:300-358): max_len-1 fused decode steps (3 GRU cells + vocab projection +
  * softmax(y/temp) + inverse-CDF draw or argmax + eos bookkeeping), no early exit, as the reference.
  * uniforms [max_len-1, n] (device) feed the draw of step i at uniforms[(i-1)*n + row]; NULL: Philox

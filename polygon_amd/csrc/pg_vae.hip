@@ -856,3 +856,32 @@ extern "C" int pg_clip_adam(long n, float* params, const float* grads, float* ex
   PG_CHECK_LAUNCH();
   return PG_OK;
 }
+
+// ---- the one entry point that allocates nothing (include/polygon_hip.h: pg_clip_adam_static) -------------------------
+// pg_clip_adam with the partial sums of squares (the only device memory of the optimiser step beyond its inputs and
+// outputs) in a library-owned array instead of a caller workspace.  Every GPU the library runs on holds its own copy of
+// the array at its own address: the address is taken once per device, with that device current, and only that pointer
+// is ever handed to kernels (the array's name is a host-side stand-in, not a device address).
+static __device__ __align__(256) float scratch[PG_SUMSQ_BLOCKS];
+constexpr int PG_STATIC_MAX_DEVICES = 64;
+static float* g_scratch_ptr[PG_STATIC_MAX_DEVICES] = {};
+
+extern "C" int pg_clip_adam_static(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int step,
+                                   float lr, float beta1, float beta2, float eps, float max_norm, float* gnorm, void* stream) {
+  PG_REQUIRE(n > 0 && n <= PG_CLIP_ADAM_STATIC_MAX_N,
+             "pg_clip_adam_static: n = %ld outside [1, %ld] (the library-owned partial-sum array is sized for that many values)", n,
+             (long)PG_CLIP_ADAM_STATIC_MAX_N);
+  int dev = -1;
+  PG_CHECK_HIP(hipGetDevice(&dev));
+  PG_REQUIRE(dev >= 0 && dev < PG_STATIC_MAX_DEVICES, "pg_clip_adam_static: device ordinal %d not supported", dev);
+  if (!g_scratch_ptr[dev]) {
+    float* p = nullptr;
+    PG_CHECK_HIP(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+    PG_REQUIRE(p != nullptr, "pg_clip_adam_static: no device address for the scratch array on device %d", dev);
+    g_scratch_ptr[dev] = p;
+  }
+  // every partial is rewritten by sumsq_kernel on each call (nothing has to start at zero), and adam_kernel reads them in
+  // stream order: calls on ONE stream are safe back to back, calls overlapping on one GPU (two streams) race on the array
+  return pg_clip_adam(n, params, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, max_norm, g_scratch_ptr[dev], gnorm,
+                      stream);
+}
