@@ -123,6 +123,25 @@ PG_API int pg_sample(const pg_dims* d, int dtype, const float* params, const voi
                      int max_len, const float* z, const float* uniforms, uint64_t seed, long row_offset, float temp,
                      int multinomial, uint8_t* tokens, int32_t* end_pads, void* stream);
 
+/* Parity hook (no reference counterpart): pg_sample with teacher forcing and a probability dump, so that the sampling
+ * kernels themselves (per-step and one-launch alike) can be compared with a CPU oracle step by step, which free-running
+ * bf16 decoding cannot be (one differently rounded draw diverges the row).  forced (nullable) uint8 [n, max_len]: the token
+ * FED to step i+1 is forced[row*max_len + i] instead of the drawn one (the drawn token is still what tokens/end_pads
+ * record).  probs_out (nullable, multinomial only) float [max_len-1, n, 64]: softmax(y/temp) of step i at
+ * probs_out[((i-1)*n + row)*64 + v], entries >= V zero.  Both NULL: exactly pg_sample. */
+PG_API int pg_sample_forced(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes,
+                            int n, int max_len, const float* z, const float* uniforms, uint64_t seed, long row_offset,
+                            float temp, int multinomial, uint8_t* tokens, int32_t* end_pads, const uint8_t* forced,
+                            float* probs_out, void* stream);
+
+/* Parity hook (no reference counterpart; HOST function, touches no GPU): the inter-layer dropout masks that
+ * pg_decoder_fwd / pg_decoder_bwd apply for (seed, p_drop, pg_dp.b_mul/b_add), computed by the same inline function the
+ * kernels call.  out (host memory) float [n_masks, B, T, H]: mask of layer l's output at decoder step t of local row b,
+ * already scaled by 1/(1-p).  torch's own nn.GRU dropout stream (vae_model.py:90) cannot be reproduced from outside, so
+ * the dropout path is pinned by feeding THESE masks to the CPU oracle. */
+PG_API int pg_dropout_masks_host(uint64_t seed, float p_drop, int n_masks, int B, int T, int H, int b_mul, int b_add,
+                                 float* out);
+
 /* Kernel-level test hooks (no reference counterpart; they expose the MFMA tile engines that every
  * entry point above is built from, so tests can check them in isolation).
  * pg_gemm_nt: C[M,N] = alpha * A[M,K] . B[N,K]^T (+bias[N]) (+C32 if accumulate) -> C32 (fp32) and/or Ct (dtype).

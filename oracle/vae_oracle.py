@@ -354,10 +354,14 @@ def inverse_cdf_draw(probs, u):
     return k.astype(np.int64), cdf
 
 
-def sample_tokens(P, z, uniforms=None, max_len=100, temp=1.0, multinomial=True, return_probs=False):
+def sample_tokens(P, z, uniforms=None, max_len=100, temp=1.0, multinomial=True, return_probs=False, forced=None,
+                  return_fed=False):
     """Token matrix of VAE.sample: returns (x [n,max_len] int64, end_pads [n]).  uniforms
     [max_len-1, n] feeds inverse_cdf_draw at each step (multinomial=True); argmax otherwise.
-    No early exit: all max_len-1 steps run for every row (vae_model.py:329)."""
+    No early exit: all max_len-1 steps run for every row (vae_model.py:329).
+    Teacher forcing for step-by-step parity checks (no counterpart in the reference): forced [n,max_len] replaces the
+    token FED to the next step (the drawn one is still what x / end_pads record); return_fed adds the matrix of tokens
+    actually fed (column i = the token drawn at step i, which the reference keeps feeding after eos, vae_model.py:330)."""
     n = z.shape[0]
     L = n_decoder_layers(P)
     h = [z @ P['decoder_lat.weight'].T + P['decoder_lat.bias'] for _ in range(L)]
@@ -366,6 +370,7 @@ def sample_tokens(P, z, uniforms=None, max_len=100, temp=1.0, multinomial=True, 
     x[:, 0] = BOS
     end_pads = np.full(n, max_len, dtype=np.int64)
     eos_mask = np.zeros(n, dtype=bool)
+    fed = np.full((n, max_len), BOS, dtype=np.int64)
     probs_log = []
     for i in range(1, max_len):
         inp = np.concatenate([P['x_emb.weight'][w], z], axis=1)
@@ -388,9 +393,15 @@ def sample_tokens(P, z, uniforms=None, max_len=100, temp=1.0, multinomial=True, 
         i_eos = (~eos_mask) & (w == EOS)
         end_pads[i_eos] = i + 1
         eos_mask |= i_eos
+        fed[:, i] = w
+        if forced is not None:
+            w = np.asarray(forced[:, i], dtype=np.int64)
+    out = (x, end_pads)
     if return_probs:
-        return x, end_pads, probs_log
-    return x, end_pads
+        out += (probs_log,)
+    if return_fed:
+        out += (fed,)
+    return out
 
 
 def tokens_to_strings(x, end_pads):

@@ -88,7 +88,7 @@ __host__ __device__ __forceinline__ uint32_t pg_mix32(uint32_t x) {
   x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ void dropout_scale4(uint64_t seed, int layer, int t, int bglob, int col4, float p, float inv_keep,
+__host__ __device__ __forceinline__ void dropout_scale4(uint64_t seed, int layer, int t, int bglob, int col4, float p, float inv_keep,
                                                float (&m)[4]) {
   const uint32_t rowkey = pg_mix32((uint32_t)seed ^ ((uint32_t)bglob * 0x9E3779B1u) ^ ((uint32_t)t * 0x85EBCA77u) ^
                                    ((uint32_t)layer * 0xC2B2AE3Du) ^ (uint32_t)(seed >> 32) * 0x27D4EB2Fu);

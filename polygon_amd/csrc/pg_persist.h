@@ -156,6 +156,11 @@ struct DecSamplePersist {
   long row_offset = 0;
   uint8_t* tokens = nullptr;                  // [n, max_len], initialised (bos, pad...) on entry
   int* end_pads = nullptr;                    // [n], = max_len on entry
+  // parity hooks (pg_sample_forced): the token FED to step i+1 of row b is forced[b * max_len + i] instead of the drawn
+  // one (the drawn one is still recorded); probs_out[((i-1) * p_stride + b) * 64 + v] receives softmax(y/temp) of step i
+  const uint8_t* forced = nullptr;
+  float* probs_out = nullptr;
+  long p_stride = 0;
   unsigned* sync = nullptr;                   // PG_SAMPLE_SYNC_WORDS words, zeroed by the launcher
   unsigned* fail = nullptr;                   // set by the launcher
 };

@@ -406,6 +406,12 @@ __device__ __forceinline__ void head_body(const DecSamplePersist& a, int g, int 
           __syncthreads();
 #pragma unroll
           for (int e = 0; e < 4; ++e) y[sq * 4 + e] = ex[e] / sum;
+          if (a.probs_out) {                                       // parity hook: the probabilities the draw below sees
+            const int b = g + NG * (16 * j + srow);
+            if (b < n)
+              *reinterpret_cast<f32x4*>(a.probs_out + ((long)(step - 1) * a.p_stride + b) * 64 + sq * 4) =
+                  f32x4{ex[0] / sum, ex[1] / sum, ex[2] / sum, ex[3] / sum};
+          }
           __syncthreads();
           if (sq == 0) {
             const int b = g + NG * (16 * j + srow);
@@ -431,7 +437,8 @@ __device__ __forceinline__ void head_body(const DecSamplePersist& a, int g, int 
         if (sq == 0) {
           const int b = g + NG * (16 * j + srow);
           if (b < n) {
-            __hip_atomic_store(a.tok + b, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // published for layer 0
+            const int fed = a.forced ? (int)a.forced[(long)b * a.max_len + step] : w;      // parity hook: teacher forcing
+            __hip_atomic_store(a.tok + b, fed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // published for layer 0
             if (!a.eos[b]) {                                       // eos[b] is only ever touched by this workgroup
               a.tokens[(long)b * a.max_len + step] = (uint8_t)w;
               if (w == a.eos_id) { a.end_pads[b] = step + 1; a.eos[b] = 1; }

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void sample_head_kernel(const typena
                                                                      long row_offset, int step, int multinomial, int eos_id,
                                                                      int max_len, uint8_t* __restrict__ tokens,
                                                                      int* __restrict__ end_pads, int* __restrict__ tok,
-                                                                     int* __restrict__ eos) {
+                                                                     int* __restrict__ eos, const uint8_t* __restrict__ forced,
+                                                                     float* __restrict__ probs_out) {
   using T = typename Cfg::T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int m0 = blockIdx.x * Cfg::BM;
@@ -84,6 +85,10 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void sample_head_kernel(const typena
       Philox4 r = philox4x32_10((uint32_t)gr, (uint32_t)(gr >> 32), (uint32_t)step, 0x5A17u, (uint32_t)seed, (uint32_t)(seed >> 32));
       u = pg_u01(r.x);
     }
+    if (probs_out) {   // parity hook: the probabilities the draw sees
+      float* po = probs_out + ((long)(step - 1) * n + b) * 64;
+      for (int v = 0; v < 64; ++v) po[v] = v < V ? y[v] / s : 0.0f;
+    }
     float cdf = 0.0f;
     w = V - 1;
     for (int v = 0; v < V; ++v) {
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void sample_head_kernel(const typena
       if (cdf > u) { w = v; break; }
     }
   }
-  tok[b] = w;
+  tok[b] = forced ? (int)forced[(long)b * max_len + step] : w;   // parity hook: teacher forcing
   if (!eos[b]) {
     tokens[(long)b * max_len + step] = (uint8_t)w;
     if (w == eos_id) { end_pads[b] = step + 1; eos[b] = 1; }
@@ -103,10 +108,16 @@ extern "C" size_t pg_sample_workspace_bytes(const pg_dims* d, int dtype, int n) 
   return sample_ws_layout(d, dtype, n).total;
 }
 
+static int sample_check_persist() {
+  PG_REQUIRE(!persist_poll_failure(), "pg_sample: a persistent kernel of this process gave up waiting for a peer workgroup");
+  return PG_OK;
+}
+
 template <typename T>
 static int sample_t(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes, int n,
                     int max_len, const float* z, const float* uniforms, uint64_t seed, long row_offset, float temp,
-                    int multinomial, uint8_t* tokens, int32_t* end_pads, hipStream_t st) {
+                    int multinomial, uint8_t* tokens, int32_t* end_pads, const uint8_t* forced, float* probs_out,
+                    hipStream_t st) {
   const ParamOff po = param_offsets(d);
   const ShadowOff so = shadow_offsets(d, dtype);
   const SampleWs w = sample_ws_layout(d, dtype, n);
@@ -158,6 +169,8 @@ static int sample_t(const pg_dims* d, int dtype, const float* params, const void
         pa.inv_temp = 1.0f / temp; pa.seed = seed; pa.row_offset = row_offset + r0;
         pa.uniforms = uniforms ? uniforms + r0 : nullptr; pa.u_stride = n;
         pa.tokens = tokens + r0 * max_len; pa.end_pads = end_pads + r0;
+        pa.forced = forced ? forced + r0 * max_len : nullptr;
+        pa.probs_out = probs_out ? probs_out + r0 * 64 : nullptr; pa.p_stride = n;
         pa.sync = at<unsigned>(ws, w.sync);
         PG_TRY(launch_dec_sample_persist(pa, st));
       }
@@ -194,21 +207,30 @@ static int sample_t(const pg_dims* d, int dtype, const float* params, const void
     PG_LAUNCH_BIG_SMEM(sample_head_kernel<HCfg>, dim3(cdiv(n, HCfg::BM)), dim3(HCfg::NTHREADS), HCfg::SMEM_BYTES, st,
                        at<T>(ws, w.hop[L - 1][p ^ 1]), n, Hd, at<T>(shadow, so.fc_w), at<float>(shadow, so.fc_b), d->V,
                        1.0f / temp, uniforms, (unsigned long long)seed, row_offset, i, multinomial, d->eos, max_len, tokens,
-                       end_pads, at<int>(ws, w.tok), at<int>(ws, w.eos));
+                       end_pads, at<int>(ws, w.tok), at<int>(ws, w.eos), forced, probs_out);
     PG_CHECK_LAUNCH();
   }
   return PG_OK;
 }
 
-extern "C" int pg_sample(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes, int n,
-                         int max_len, const float* z, const float* uniforms, uint64_t seed, long row_offset, float temp,
-                         int multinomial, uint8_t* tokens, int32_t* end_pads, void* stream) {
+extern "C" int pg_sample_forced(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes,
+                                int n, int max_len, const float* z, const float* uniforms, uint64_t seed, long row_offset,
+                                float temp, int multinomial, uint8_t* tokens, int32_t* end_pads, const uint8_t* forced,
+                                float* probs_out, void* stream) {
   PG_TRY(check_dims(d, dtype));
   PG_REQUIRE(params && shadow && ws && z && tokens && end_pads, "pg_sample: NULL buffer");
   PG_REQUIRE(n >= 1, "pg_sample: n must be >= 1");
-  PG_REQUIRE(!persist_poll_failure(), "pg_sample: a persistent kernel of this process gave up waiting for a peer workgroup");
+  PG_REQUIRE(!probs_out || multinomial, "pg_sample_forced: probabilities are only computed when multinomial != 0");
+  PG_TRY(sample_check_persist());
   return dtype == PG_BF16 ? sample_t<bf16_t>(d, dtype, params, shadow, ws, ws_bytes, n, max_len, z, uniforms, seed, row_offset,
-                                             temp, multinomial, tokens, end_pads, (hipStream_t)stream)
+                                             temp, multinomial, tokens, end_pads, forced, probs_out, (hipStream_t)stream)
                           : sample_t<float>(d, dtype, params, shadow, ws, ws_bytes, n, max_len, z, uniforms, seed, row_offset,
-                                            temp, multinomial, tokens, end_pads, (hipStream_t)stream);
+                                            temp, multinomial, tokens, end_pads, forced, probs_out, (hipStream_t)stream);
+}
+
+extern "C" int pg_sample(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes, int n,
+                         int max_len, const float* z, const float* uniforms, uint64_t seed, long row_offset, float temp,
+                         int multinomial, uint8_t* tokens, int32_t* end_pads, void* stream) {
+  return pg_sample_forced(d, dtype, params, shadow, ws, ws_bytes, n, max_len, z, uniforms, seed, row_offset, temp, multinomial,
+                          tokens, end_pads, nullptr, nullptr, stream);
 }

@@ -857,6 +857,28 @@ extern "C" int pg_clip_adam(long n, float* params, const float* grads, float* ex
   return PG_OK;
 }
 
+// ---- parity hook: the inter-layer dropout masks of pg_decoder_fwd / pg_decoder_bwd, computed on the HOST by the very
+// function the kernels call (dropout_scale4, pg_common.h), so that a test can hand the same masks to a CPU oracle.
+// out (host) [n_masks][B][T][H]: mask of layer l's output (l = 0 .. n_masks-1) at decoder step t of local row b, already
+// scaled by 1/(1-p).
+extern "C" int pg_dropout_masks_host(uint64_t seed, float p_drop, int n_masks, int B, int T, int H, int b_mul, int b_add,
+                                     float* out) {
+  PG_REQUIRE(out && n_masks >= 0 && B >= 1 && T >= 1 && H >= 4 && H % 4 == 0, "pg_dropout_masks_host: bad arguments");
+  PG_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "pg_dropout_masks_host: dropout %f outside [0,1)", p_drop);
+  const float inv_keep = p_drop > 0.0f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  for (int l = 0; l < n_masks; ++l)
+    for (int b = 0; b < B; ++b)
+      for (int t = 0; t < T; ++t) {
+        float* o = out + (((size_t)l * B + b) * T + t) * H;
+        for (int c4 = 0; c4 < H / 4; ++c4) {
+          float m[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+          if (p_drop > 0.0f) dropout_scale4(seed, l, t, b * b_mul + b_add, c4, p_drop, inv_keep, m);
+          o[4 * c4] = m[0]; o[4 * c4 + 1] = m[1]; o[4 * c4 + 2] = m[2]; o[4 * c4 + 3] = m[3];
+        }
+      }
+  return PG_OK;
+}
+
 // ---- the one entry point that allocates nothing (include/polygon_hip.h: pg_clip_adam_static) -------------------------
 // pg_clip_adam with the partial sums of squares (the only device memory of the optimiser step beyond its inputs and
 // outputs) in a library-owned array instead of a caller workspace.  Every GPU the library runs on holds its own copy of

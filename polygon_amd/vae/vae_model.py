@@ -549,9 +549,11 @@ class VAE(nn.Module):
         return z
 
     def sample_tokens(self, n_batch, max_len=100, z=None, temp=1.0, multinomial=True, uniforms=None, seed=None,
-                      row_offset=0):
+                      row_offset=0, forced=None, return_probs=False):
         """Token matrix of ``sample``: (tokens uint8 [n, max_len], end_pads int32 [n]) on the device.
-        ``uniforms`` [max_len-1, n] pins the inverse-CDF draws (parity mode); otherwise Philox(seed, row, step)."""
+        ``uniforms`` [max_len-1, n] pins the inverse-CDF draws (parity mode); otherwise Philox(seed, row, step).
+        Parity hooks (pg_sample_forced): ``forced`` uint8 [n, max_len] teacher-forces the token fed to every step;
+        ``return_probs`` adds the per-step probabilities float [max_len-1, n, 64] as a third result."""
         eng = self._engine
         with torch.no_grad():
             eng.ensure_shadow()
@@ -575,12 +577,20 @@ class VAE(nn.Module):
                     raise RuntimeError("uniforms must have shape [max_len-1, n_batch]")
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            _lib.check(L.pg_sample(ctypes.byref(eng.dims), eng.dtype_code(), _lib.ptr(eng.flat), _lib.ptr(eng.shadow),
-                                   _lib.ptr(ws), ctypes.c_size_t(nbytes), int(n_batch), int(max_len), _lib.ptr(z),
-                                   _lib.ptr(uniforms), ctypes.c_uint64(seed), ctypes.c_long(int(row_offset)),
-                                   ctypes.c_float(float(temp)), int(bool(multinomial)), _lib.ptr(tokens), _lib.ptr(end_pads),
-                                   _lib.stream_ptr()), "pg_sample")
-            return tokens, end_pads
+            args = [ctypes.byref(eng.dims), eng.dtype_code(), _lib.ptr(eng.flat), _lib.ptr(eng.shadow), _lib.ptr(ws),
+                    ctypes.c_size_t(nbytes), int(n_batch), int(max_len), _lib.ptr(z), _lib.ptr(uniforms),
+                    ctypes.c_uint64(seed), ctypes.c_long(int(row_offset)), ctypes.c_float(float(temp)),
+                    int(bool(multinomial)), _lib.ptr(tokens), _lib.ptr(end_pads)]
+            if forced is None and not return_probs:
+                _lib.check(L.pg_sample(*args, _lib.stream_ptr()), "pg_sample")
+                return tokens, end_pads
+            probs = torch.zeros(max_len - 1, n_batch, 64, device=dev) if return_probs else None
+            if forced is not None:
+                forced = forced.to(dev, torch.uint8).contiguous()
+                if tuple(forced.shape) != (n_batch, max_len):
+                    raise RuntimeError("forced must have shape [n_batch, max_len]")
+            _lib.check(L.pg_sample_forced(*args, _lib.ptr(forced), _lib.ptr(probs), _lib.stream_ptr()), "pg_sample_forced")
+            return (tokens, end_pads, probs) if return_probs else (tokens, end_pads)
 
     def sample(self, n_batch, max_len=100, z=None, temp=1.0, multinomial=True):
         """vae_model.py:300-358 -> list of strings (no early exit; specials mid-stream rendered literally)."""

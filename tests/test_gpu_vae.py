@@ -52,7 +52,7 @@ def test_gradients_match_reference(golden_dir, tag, dims, seed, full, dt):
     kl, recon = model(batch)
     loss = float(g["kl_w"]) * kl + recon
     loss.backward()
-    tol = 1e-2 if dt == "fp32" else 5e-2
+    tol = 1e-2     # north_star: gradients within 1e-2 relative, fp32 and bf16 alike (bf16 measured: <= 4e-3 per tensor)
     for k, p in canon_named(model).items():
         got = p.grad.detach().cpu().numpy()
         if full:
@@ -122,7 +122,7 @@ def test_batch_vs_oracle_ragged(dt):
     tol = TOL[dt]
     assert abs(kl.item() - enc["kl"]) <= tol * abs(enc["kl"])
     assert abs(recon.item() - dec["recon"]) <= tol * abs(dec["recon"])
-    gtol = 1e-2 if dt == "fp32" else 5e-2
+    gtol = 1e-2     # north_star: gradients within 1e-2 relative, fp32 and bf16 alike (bf16 measured: <= 4e-3 per tensor)
     for k, p in canon_named(model).items():
         assert rel_err(p.grad, G[k]) <= gtol, k
 
