@@ -5,10 +5,20 @@
  * point below replaces the torch call sites named in its comment (file:line relative to the
  * reference root); the Python mirror of the reference API that binds them is polygon_amd/vae/.
  *
- * Conventions: every function returns 0 or a negative PG_ERR_* code; pg_last_error() returns the
+ * Conventions: every function returns 0 or a negative PG_ERR_* code (-1 argument, -2 HIP, -3 unsupported,
+ * -4 workspace, -5 a persistent kernel gave up: see pg_check_failure); pg_last_error() returns the
  * calling thread's last message.  Device pointers are raw HIP pointers; work is enqueued on the
- * caller's stream (hipStream_t passed as void*); the library allocates nothing, keeps no global
- * mutable state and performs no host synchronisation.  No C++ exception crosses the boundary.
+ * caller's stream (hipStream_t passed as void*) with no host synchronisation, and every per-call
+ * buffer (workspaces sized by pg_*_workspace_bytes) is the caller's.  No C++ exception crosses the
+ * boundary.
+ *
+ * Library-owned state (process-wide, NOT thread-safe: one process per GPU, one calling thread at a
+ * time is the model): (1) a 64-byte device word + 64-byte pinned host mirror "a persistent kernel
+ * gave up", allocated on the first persistent launch and never freed; (2) the side stream and two
+ * events of pg_defer_weight_grads, created on first use; (3) up to 2 x 512 HIP event pairs while
+ * pg_profile_enable is on; (4) the switches set by pg_persist_disable / pg_defer_weight_grads /
+ * pg_profile_enable / pg_persist_spin_limit (read once from PG_NO_PERSIST at first use); (5) the 2-KiB
+ * static device array of pg_clip_adam_static.  Nothing else persists between calls.
  *
  * Parameters are ONE flat fp32 buffer in the order of model.vae.parameters()
  * (vae_model.py:101-115, = optimiser order vae_trainer.py:99-100):
@@ -157,11 +167,12 @@ PG_API int pg_gemm_tn(int dtype, const void* A, long lda, const void* B, long ld
 PG_API int pg_bench_gru(int dtype, int which, int rows, int H, void* ws, size_t ws_bytes, int repeat, void* stream);
 
 /* Measurement hook (no reference counterpart): while enabled, pg_decoder_fwd / pg_decoder_bwd bracket their
- * recurrence (the wavefront loop, which launches nothing but the diagonal step kernel) with a HIP event pair
- * recorded on the caller's stream and count the loop's launches and algorithmic flop.  pg_profile_read waits for
- * the recorded events, returns the sums since the last read for which = 0 (forward recurrence,
- * gru_fwd2_diag_kernel) or 1 (BPTT recurrence, gru_bwd2_diag_kernel) and clears that side.  At most 512 segments
- * are kept per side between reads; later ones are dropped (not counted). */
+ * recurrence - ONE launch of dec_fwd_persist_kernel / dec_bwd_persist_kernel where the persistent kernels cover the
+ * shape (bf16, Hd = 512), otherwise the loop of gru_fwd2_diag_kernel / gru_bwd2_diag_kernel launches, one per
+ * anti-diagonal of the (layer, t) grid - with a HIP event pair recorded on the caller's stream and count its launches
+ * and algorithmic flop.  pg_profile_read waits for the recorded events, returns the sums since the last read for
+ * which = 0 (forward recurrence) or 1 (BPTT recurrence) and clears that side.  At most 512 segments are kept per side
+ * between reads; later ones are dropped (not counted). */
 PG_API int pg_profile_enable(int on);
 PG_API int pg_profile_read(int which, double* total_ms, long* launches, double* flop, int* segments);
 
@@ -173,6 +184,17 @@ PG_API int pg_profile_read(int which, double* total_ms, long* launches, double* 
  * without any of the three must leave this off.  pg_defer_weight_grads returns the previous setting (on < 0: query). */
 PG_API int pg_defer_weight_grads(int on);
 PG_API int pg_deferred_join(void* stream);
+
+/* Failure of a persistent recurrence kernel (no reference counterpart).  The group-persistent kernels' workgroups wait
+ * for each other; every wait is bounded (pg_persist_spin_limit polls, default 2^21 = 2-4 s), and a workgroup that gives up
+ * sets a sticky device word.  Device side: pg_clip_adam's kernel reads the word and SKIPS the update, so garbage
+ * gradients never reach the weights.  Host side: every entry point checks the word's pinned mirror on entry and
+ * pg_check_failure(stream) synchronises `stream` first (call it before trusting or saving results).  The call that
+ * detects a failure returns PG_ERR_PERSIST once; the library then clears the word and switches every recurrence to the
+ * per-step kernels (as pg_persist_disable(15)), so later calls work.  pg_persist_spin_limit(limit) sets the poll bound and
+ * returns the previous one (limit < 0: query; 0 makes every unsatisfied wait give up at once - the test hook). */
+PG_API int pg_check_failure(void* stream);
+PG_API unsigned pg_persist_spin_limit(long limit);
 
 /* Test / A-B hook (no reference counterpart): the recurrences run as persistent kernels where the shape is covered
  * (bf16, Hq = 256, Hd = 512); mask bits force the per-step kernels instead: 1 encoder, 2 decoder forward, 4 decoder BPTT,

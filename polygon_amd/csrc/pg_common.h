@@ -17,6 +17,7 @@ extern thread_local char g_pg_err[512];
 #define PG_ERR_HIP (-2)
 #define PG_ERR_UNSUPPORTED (-3)
 #define PG_ERR_WORKSPACE (-4)
+#define PG_ERR_PERSIST (-5)
 
 #define PG_FAIL(code, ...)                          \
   do {                                              \

@@ -258,7 +258,11 @@ static __global__ void sumsq_kernel(const float* __restrict__ g, long n, float* 
 }
 static __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, const float* __restrict__ partial, int npartial, float max_norm, float step_size,
-                            float beta1, float beta2, float inv_sqrt_bc2, float eps, float* __restrict__ gnorm_out) {
+                            float beta1, float beta2, float inv_sqrt_bc2, float eps, float* __restrict__ gnorm_out,
+                            const unsigned* __restrict__ fail) {
+  // a persistent recurrence kernel of this step gave up (sticky device word): its gradients are garbage, so the update is
+  // skipped here, on the device, with no host round trip; the host reports the failure at its next check
+  if (fail && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   __shared__ float red[256];
   float s = 0.0f;
   for (int i = threadIdx.x; i < npartial; i += blockDim.x) s += partial[i];

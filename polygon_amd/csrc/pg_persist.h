@@ -68,6 +68,7 @@ struct DecFwdPersist {
   int b_mul = 1, b_add = 0;
   unsigned* sync = nullptr;                   // PG_PERSIST_SYNC_WORDS words, zeroed by the launcher
   unsigned* fail = nullptr;                   // set by the launcher: process-wide sticky give-up word
+  unsigned spin_limit = 0;                    // set by the launcher: polls before a waiting workgroup gives up
   unsigned long long* stamps = nullptr;       // development aid: wall-clock stamps of one workgroup (pg_persist_stamps)
   int dbg = 0;                                // development aid (PG_PERSIST_DBG): 1 no DMA, 2 no MFMA, 4 no epilogue stores, 8 no epilogue loads
 };
@@ -124,6 +125,7 @@ struct DecBwdPersist {
   int b_mul = 1, b_add = 0;
   unsigned* sync = nullptr;                   // PG_PERSIST_SYNC_WORDS words, zeroed by the launcher
   unsigned* fail = nullptr;                   // set by the launcher
+  unsigned spin_limit = 0;                    // set by the launcher
   unsigned long long* stamps = nullptr;       // development aid (pg_persist_stamps)
   int dbg = 0;                                // development aid (PG_PERSIST_DBG): 1 no DMA, 2 no MFMA, 4 no epilogue I/O
 };
@@ -163,6 +165,7 @@ struct DecSamplePersist {
   long p_stride = 0;
   unsigned* sync = nullptr;                   // PG_SAMPLE_SYNC_WORDS words, zeroed by the launcher
   unsigned* fail = nullptr;                   // set by the launcher
+  unsigned spin_limit = 0;                    // set by the launcher
 };
 bool dec_sample_persist_supported(int Hd, int L, int V, long n);
 int launch_dec_sample_persist(DecSamplePersist& a, hipStream_t stream);
@@ -179,8 +182,16 @@ int persist_fail_words(unsigned** dev);
 int persist_fail_mirror(hipStream_t stream);
 bool persist_dma_plain();
 unsigned long long* persist_stamps_for(int which);   // development aid: stamp buffer if tracing kernel `which`, else null
-// nonzero once a persistent kernel of this process gave up waiting on another workgroup (checked by every entry point)
+// nonzero once a persistent kernel of this process gave up waiting on another workgroup (checked by every entry point);
+// reads the pinned mirror, which is current once the launching stream has been synchronised
 int persist_poll_failure();
+// device address of the sticky word, or null while no persistent kernel has been launched (pg_clip_adam hands it to the
+// Adam kernel, which skips the update when it is set)
+unsigned* persist_fail_dev_or_null();
+// after a detected give-up: waits for the device, clears both words and switches every recurrence to the per-step kernels
+int persist_recover();
+// polls a waiting workgroup makes before it gives up (default 2^21, ~2-4 s); pg_persist_spin_limit() overrides it
+unsigned persist_spin_limit();
 
 // true when the persistent kernels cover this hidden size (others take the per-step path)
 bool enc_persist_supported(int H);

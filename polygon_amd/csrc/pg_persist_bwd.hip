@@ -51,11 +51,11 @@ __device__ __forceinline__ void store_pub_b64(__amdgpu_buffer_rsrc_t r, unsigned
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, (int)byte_off, 0, AUXS);
 }
 
-__device__ __forceinline__ bool wait_ge(unsigned* p, unsigned target, unsigned* err, unsigned* sticky) {
+__device__ __forceinline__ bool wait_ge(unsigned* p, unsigned target, unsigned* err, unsigned* sticky, unsigned limit) {
   for (unsigned spins = 0;; ++spins) {
     if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
     if ((spins & 63u) == 63u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-    if (spins > SPIN_LIMIT) {
+    if (spins > limit) {
       __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return false;
@@ -157,8 +157,8 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
     PG_STAMP(0);
     // ---- wait for dGH_{l,t+1} (own layer) and dGI_{l+1,t} (layer above)
     if (tid == 0) {
-      bool ok = wait_ge(cnt_own, (unsigned)(NCU * s), err, a.fail);
-      if (has_up && ok) ok = wait_ge(cnt_up, (unsigned)(NCU * (s + 1)), err, a.fail);
+      bool ok = wait_ge(cnt_own, (unsigned)(NCU * s), err, a.fail, a.spin_limit);
+      if (has_up && ok) ok = wait_ge(cnt_up, (unsigned)(NCU * (s + 1)), err, a.fail, a.spin_limit);
       PG_STAMP(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -463,6 +463,7 @@ int launch_dec_bwd_persist(DecBwdPersist& a, const Sched& sd, int H, float* dh0_
   constexpr int SMEM = GL::SMEM > GT::SMEM ? GL::SMEM : GT::SMEM;
   a.NG = persist_groups(a.L, a.B);
   PG_TRY(persist_fail_words(&a.fail));
+  a.spin_limit = persist_spin_limit();
   a.stamps = persist_stamps_for(1);
   a.dbg = getenv("PG_PERSIST_DBG") ? atoi(getenv("PG_PERSIST_DBG")) : 0;
   PG_CHECK_HIP(hipMemsetAsync(a.sync, 0, PG_PERSIST_SYNC_WORDS * sizeof(unsigned), stream));

@@ -65,11 +65,11 @@ __device__ __forceinline__ uint4 load_sc1_b128(__amdgpu_buffer_rsrc_t r, unsigne
 }
 
 // one lane: wait until *p >= target.  false: this or another workgroup gave up (err word set).
-__device__ __forceinline__ bool wait_ge(unsigned* p, unsigned target, unsigned* err, unsigned* sticky) {
+__device__ __forceinline__ bool wait_ge(unsigned* p, unsigned target, unsigned* err, unsigned* sticky, unsigned limit) {
   for (unsigned spins = 0;; ++spins) {
     if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
     if ((spins & 63u) == 63u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-    if (spins > SPIN_LIMIT) {
+    if (spins > limit) {
       __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return false;
@@ -204,8 +204,8 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
     PG_STAMP(0);
     // ---- wait for h_{l,t-1} (own layer) and x = h_{l-1,t} (layer below)
     if (tid == 0) {
-      bool ok = wait_ge(cnt_own, (unsigned)(NCU * t), err, a.fail);
-      if (!L0 && ok) ok = wait_ge(cnt_low, (unsigned)(NCU * (t + 1)), err, a.fail);
+      bool ok = wait_ge(cnt_own, (unsigned)(NCU * t), err, a.fail, a.spin_limit);
+      if (!L0 && ok) ok = wait_ge(cnt_low, (unsigned)(NCU * (t + 1)), err, a.fail, a.spin_limit);
       PG_STAMP(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -458,7 +458,8 @@ __global__ __launch_bounds__(256) void dec_fwd_persist_kernel(DecFwdPersist a, S
 unsigned long long* g_stamps = nullptr;
 int g_stamps_which = 0;            // 0: forward kernel, 1: BPTT kernel
 int* g_fail_host = nullptr;        // pinned mirror of the sticky give-up word
-unsigned* g_fail_dev = nullptr;   // never cleared: one timed-out launch condemns the process
+unsigned* g_fail_dev = nullptr;   // sticky until persist_recover()
+unsigned g_spin_limit = SPIN_LIMIT;
 
 }  // namespace
 
@@ -485,6 +486,22 @@ int persist_fail_words(unsigned** dev) {
   return PG_OK;
 }
 
+unsigned* persist_fail_dev_or_null() { return g_fail_dev; }
+unsigned persist_spin_limit() { return g_spin_limit; }
+extern "C" __attribute__((visibility("default"))) unsigned pg_persist_spin_limit(long limit) {
+  const unsigned old = g_spin_limit;
+  if (limit >= 0) g_spin_limit = limit > 0xFFFFFFF0L ? 0xFFFFFFF0u : (unsigned)limit;
+  return old;
+}
+
+int persist_recover() {
+  if (!g_fail_host) return PG_OK;
+  PG_CHECK_HIP(hipDeviceSynchronize());
+  PG_CHECK_HIP(hipMemset(g_fail_dev, 0, 64));
+  *g_fail_host = 0;
+  return PG_OK;
+}
+
 int persist_fail_mirror(hipStream_t stream) {
   PG_CHECK_HIP(hipMemcpyAsync(g_fail_host, g_fail_dev, sizeof(unsigned), hipMemcpyDeviceToHost, stream));
   return PG_OK;
@@ -496,6 +513,7 @@ int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t
   using G = DecGeo<512>;
   a.NG = persist_groups(a.L, a.B);
   PG_TRY(persist_fail_words(&a.fail));
+  a.spin_limit = persist_spin_limit();
   a.stamps = g_stamps_which == 0 ? g_stamps : nullptr;
   a.dbg = getenv("PG_PERSIST_DBG") ? atoi(getenv("PG_PERSIST_DBG")) : 0;
   PG_CHECK_HIP(hipMemsetAsync(a.sync, 0, PG_PERSIST_SYNC_WORDS * sizeof(unsigned), stream));

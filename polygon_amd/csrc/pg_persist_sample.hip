@@ -59,11 +59,11 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float (&v)[4]) {
   return o;
 }
 
-__device__ __forceinline__ bool wait_ge(unsigned* p, unsigned target, unsigned* err, unsigned* sticky) {
+__device__ __forceinline__ bool wait_ge(unsigned* p, unsigned target, unsigned* err, unsigned* sticky, unsigned limit) {
   for (unsigned spins = 0;; ++spins) {
     if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
     if ((spins & 63u) == 63u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-    if (spins > SPIN_LIMIT) {
+    if (spins > limit) {
       __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return false;
@@ -146,10 +146,10 @@ __device__ __forceinline__ void layer_body(const DecSamplePersist& a, int g, int
       const int j1 = j0 + a.TS < a.ntile ? j0 + a.TS : a.ntile;
       // ---- wait for (l, t-1, s) of every slice and for the stage below: (l-1, t, s), or the head's (t-1, s)
       if (tid == 0) {
-        bool ok = wait_ge(counter(a, g, l, s), (unsigned)(NCU * t), err, a.fail);
+        bool ok = wait_ge(counter(a, g, l, s), (unsigned)(NCU * t), err, a.fail, a.spin_limit);
         if (ok) {
-          if constexpr (L0) ok = wait_ge(counter(a, g, NSTAGE - 1, s), (unsigned)(NH * t), err, a.fail);
-          else ok = wait_ge(counter(a, g, l - 1, s), (unsigned)(NCU * (t + 1)), err, a.fail);
+          if constexpr (L0) ok = wait_ge(counter(a, g, NSTAGE - 1, s), (unsigned)(NH * t), err, a.fail, a.spin_limit);
+          else ok = wait_ge(counter(a, g, l - 1, s), (unsigned)(NCU * (t + 1)), err, a.fail, a.spin_limit);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -344,7 +344,7 @@ __device__ __forceinline__ void head_body(const DecSamplePersist& a, int g, int 
       const int j0 = s * a.TS;
       const int j1 = j0 + a.TS < a.ntile ? j0 + a.TS : a.ntile;
       if (tid == 0) {
-        const bool ok = wait_ge(counter(a, g, top, s), (unsigned)(NCU * (t + 1)), err, a.fail);
+        const bool ok = wait_ge(counter(a, g, top, s), (unsigned)(NCU * (t + 1)), err, a.fail, a.spin_limit);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         *sFlagT = ok ? 1u : 0u;
@@ -499,6 +499,7 @@ int launch_dec_sample_persist(DecSamplePersist& a, hipStream_t stream) {
   a.S = (a.ntile + TS - 1) / TS;
   PG_REQUIRE(a.S >= 1 && a.S <= PG_SAMPLE_MAX_SUB, "dec_sample_persist: %d sub-batches", a.S);
   PG_TRY(persist_fail_words(&a.fail));
+  a.spin_limit = persist_spin_limit();
   PG_CHECK_HIP(hipMemsetAsync(a.sync, 0, PG_SAMPLE_SYNC_WORDS * sizeof(unsigned), stream));
   static bool attr_done = false;
   if (!attr_done) {

@@ -108,10 +108,8 @@ extern "C" size_t pg_sample_workspace_bytes(const pg_dims* d, int dtype, int n) 
   return sample_ws_layout(d, dtype, n).total;
 }
 
-static int sample_check_persist() {
-  PG_REQUIRE(!persist_poll_failure(), "pg_sample: a persistent kernel of this process gave up waiting for a peer workgroup");
-  return PG_OK;
-}
+int check_persist();   // pg_vae.hip
+static int sample_check_persist() { return check_persist(); }
 
 template <typename T>
 static int sample_t(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes, int n,

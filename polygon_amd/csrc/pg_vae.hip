@@ -185,13 +185,22 @@ extern "C" int pg_persist_disable(int mask) {
 }
 static bool use_persistent(int H) { return !(persist_off_mask() & 1) && enc_persist_supported(H); }
 
-// a persistent kernel of an earlier call gave up waiting for a peer workgroup (it was not co-resident): everything computed
-// since is suspect, so every later call fails loudly instead of returning numbers
-static int check_persist() {
-  PG_REQUIRE(persist_poll_failure() == 0,
-             "a persistent recurrence kernel timed out waiting for its peer workgroups (GPU shared or partially available?); "
-             "set PG_NO_PERSIST=7 to use the per-step kernels");
-  return PG_OK;
+// A persistent kernel of an earlier call gave up waiting for a peer workgroup (its grid was not co-resident: GPU shared or
+// partially available).  Everything computed since that launch is suspect - the Adam kernel has skipped its updates on
+// seeing the device word - so THIS call fails, loudly, once; the library then clears the word and switches every
+// recurrence to the per-step kernels, which need no co-residency, so later calls work (pg_persist_disable(0) re-enables).
+int check_persist() {
+  if (persist_poll_failure() == 0) return PG_OK;
+  PG_TRY(persist_recover());
+  g_persist_off = 15;
+  PG_FAIL(PG_ERR_PERSIST,
+          "a persistent recurrence kernel timed out waiting for its peer workgroups (GPU shared or partially available?): "
+          "the results since that launch are invalid and optimiser updates were skipped; later calls use the per-step kernels");
+}
+
+extern "C" int pg_check_failure(void* stream) {
+  PG_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return check_persist();
 }
 
 // ---- deferred weight gradients: the decoder's large weight-gradient GEMMs run on a library-owned side stream, beside the
@@ -846,13 +855,14 @@ extern "C" int pg_clip_adam(long n, float* params, const float* grads, float* ex
                             float beta1, float beta2, float eps, float max_norm, float* scratch, float* gnorm, void* stream) {
   PG_REQUIRE(n > 0 && params && grads && exp_avg && exp_avg_sq && scratch, "pg_clip_adam: NULL buffer");
   PG_REQUIRE(step >= 1, "pg_clip_adam: step must be >= 1");
+  PG_TRY(check_persist());
   hipStream_t st = (hipStream_t)stream;
   PG_TRY(defer_join(st, true));
   hipLaunchKernelGGL(sumsq_kernel, dim3(PG_SUMSQ_BLOCKS), dim3(256), 0, st, grads, n, scratch);
   PG_CHECK_LAUNCH();
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, scratch,
-                     (int)PG_SUMSQ_BLOCKS, max_norm, (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps, gnorm);
+                     (int)PG_SUMSQ_BLOCKS, max_norm, (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps, gnorm, persist_fail_dev_or_null());
   PG_CHECK_LAUNCH();
   return PG_OK;
 }

@@ -1,8 +1,8 @@
 """Data parallelism for VAE training: one process per GPU, gradients summed with RCCL over xGMI.
 
 The reference has no multi-GPU code at all (polygon/run.py:611-612 is a comment).  Scheme: every rank
-collates the SAME global batch (same shuffle), which is sorted by length, and takes rows rank, rank+G, ... so its
-shard stays sorted and length-balanced.  Losses are normalised by GLOBAL counts inside the kernels (pg_dp), so the
+draws the SAME global batch of strings (same shuffle), sorts it on lengths only, keeps rows rank, rank+G, ... (its shard
+stays sorted and length-balanced) and tokenises / uploads just those (VAE.get_collate_fn(shard=...)).  Losses are normalised by GLOBAL counts inside the kernels (pg_dp), so the
 SUM all-reduce of the per-rank gradients equals the single-process gradient of the global batch.  The flat gradient
 buffer is reduced in two buckets: the decoder bucket (~92 % of the bytes) as soon as the decoder BPTT has finished,
 overlapping the encoder BPTT; the encoder/embedding bucket afterwards.  Clip + Adam then run redundantly per rank.
@@ -37,21 +37,77 @@ def world_info():
 
 
 class GradComm:
-    """Two-bucket SUM all-reduce of the flat gradient buffer, decoder bucket overlapped with the encoder BPTT."""
+    """Two-bucket SUM all-reduce of the flat gradient buffer, decoder bucket overlapped with the encoder BPTT.
+
+    The decoder bucket is reduced on a communication stream of its own: that stream waits for (a) everything the caller's
+    stream has enqueued up to the end of pg_decoder_bwd and (b) the library's side stream, on which the decoder's large
+    weight-gradient GEMMs run (pg_deferred_join) - so the GEMMs, the all-reduce and the encoder BPTT (caller's stream)
+    overlap, and the caller's stream itself never waits for the GEMMs before the encoder BPTT.  ``finish`` reduces the
+    encoder / embedding bucket and makes the caller's stream wait for both."""
 
     def __init__(self, group=None):
         self.group = group
         self.work = None
+        self.stream = None
+        # gloo (CPU rehearsals, two ranks sharing one GPU in the tests) moves device tensors through host copies; the
+        # deployment backend is nccl (= RCCL on ROCm), which reduces in place on the device
+        self.staged = dist.get_backend(group) != "nccl"
+
+    def _join_deferred(self, stream):
+        import ctypes
+        from polygon_amd import _lib
+        _lib.check(_lib.lib().pg_deferred_join(ctypes.c_void_p(stream.cuda_stream)), "pg_deferred_join")
+
+    def _staged_sum(self, t):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+        t.copy_(h)
 
     def start_decoder_bucket(self, grads, dec_start):
-        self.work = dist.all_reduce(grads[dec_start:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if not grads.is_cuda:
+            self.work = dist.all_reduce(grads[dec_start:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            return
+        main = torch.cuda.current_stream(grads.device)
+        if self.staged:
+            self._join_deferred(main)
+            self._staged_sum(grads[dec_start:])
+            return
+        if self.stream is None or self.stream.device != grads.device:
+            self.stream = torch.cuda.Stream(device=grads.device)
+        self.stream.wait_stream(main)
+        self._join_deferred(self.stream)
+        with torch.cuda.stream(self.stream):
+            self.work = dist.all_reduce(grads[dec_start:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self, grads, dec_start):
+        if grads.is_cuda and self.staged:
+            self._staged_sum(grads[:dec_start])
+            return
         w2 = dist.all_reduce(grads[:dec_start], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if self.work is not None:
-            self.work.wait()
+            self.work.wait()                 # the caller's (current) stream waits for the decoder bucket
+            if grads.is_cuda:
+                torch.cuda.current_stream(grads.device).wait_stream(self.stream)
             self.work = None
         w2.wait()
+
+    def sum_scalars(self, t):
+        """In-place SUM all-reduce of a small tensor of per-rank partial losses (the kernels normalise by GLOBAL counts,
+        so the sum over ranks is the global-batch value)."""
+        if t.is_cuda and self.staged:
+            self._staged_sum(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def broadcast(self, t, src=0):
+        if t.is_cuda and self.staged:
+            h = t.cpu()
+            dist.broadcast(h, src, group=self.group)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src, group=self.group)
+        return t
 
 
 def global_batch_stats(lengths_global):

@@ -51,6 +51,11 @@ class TokenBatch(list):
         self.lengths = np.ascontiguousarray(lengths, dtype=np.int32)
         self.strings = strings
         self._items = None
+        # data parallelism (set by a sharding collate): this rank's pg_dp of the global batch, the global batch's row and
+        # token counts, and the global row index of each local row (None: the batch is not a shard)
+        self.dp = None
+        self.global_rows = int(self.lengths.shape[0])
+        self.global_tokens = int(self.lengths.sum())
 
     def _mat(self):
         if self._items is None:
@@ -72,9 +77,18 @@ class TokenBatch(list):
         return int(self.lengths.sum())
 
     def shard(self, rank, world):
-        """Rows rank, rank+world, ... of the (already length-sorted) batch: each shard stays sorted."""
+        """Rows rank, rank+world, ... of the (already length-sorted) batch: each shard stays sorted.  The shard carries
+        the pg_dp that normalises its losses by the GLOBAL counts (include/polygon_hip.h)."""
         idx = torch.arange(rank, len(self), world, device=self.tokens.device)
-        return TokenBatch(self.tokens.index_select(0, idx).contiguous(), self.lengths[rank::world])
+        out = TokenBatch(self.tokens.index_select(0, idx).contiguous(), self.lengths[rank::world])
+        out.set_global(rank, world, len(self), self.n_tokens)
+        return out
+
+    def set_global(self, rank, world, global_rows, global_tokens):
+        self.global_rows, self.global_tokens = int(global_rows), int(global_tokens)
+        # every row contributes len-1 cross-entropy targets (the tokeniser never emits pad)
+        self.dp = _Dp(kl_inv_batch=1.0 / max(1, self.global_rows), ce_count=float(self.global_tokens - self.global_rows),
+                      b_mul=int(world), b_add=int(rank))
 
 
 def _as_batch(x, pad, device):
@@ -250,14 +264,17 @@ class _Engine:
             sm = self._small = (torch.empty(max(B, 64), self.dims.Dz, device=dev), torch.empty(max(B, 64), self.dims.Dz, device=dev),
                                 torch.empty(2, device=dev))
         z, dz, scal = sm
+        if dp is None:
+            dp = getattr(batch, "dp", None)        # a shard made by the sharding collate carries its own pg_dp
         if eps is None:
             eps = torch.randn(B, self.dims.Dz, device=dev)
         grads.zero_()
         self.encoder_fwd(ws, batch, eps, dp, 1, z, None, None, scal[0:1])
         self.decoder_fwd(ws, batch, z, dp, p_drop, seed, 0, 1, scal[1:2])
-        # the decoder's large weight-gradient GEMMs run beside the encoder BPTT (side stream inside the library; joined
-        # at the end of pg_encoder_bwd).  Under data parallelism the decoder bucket's all-reduce needs them first.
-        old = L.pg_defer_weight_grads(0 if comm is not None else 1)
+        # the decoder's large weight-gradient GEMMs run on the library's side stream, beside the dz chain and the encoder
+        # BPTT (joined at the end of pg_encoder_bwd).  Under data parallelism the decoder bucket's all-reduce waits for
+        # them on the communication stream (GradComm.start_decoder_bucket), not on this one.
+        old = L.pg_defer_weight_grads(1)
         try:
             self.decoder_bwd(ws, batch, dp, p_drop, seed, 0, 1.0, None, grads, dz)
             if comm is not None:
@@ -267,6 +284,28 @@ class _Engine:
             L.pg_defer_weight_grads(old)
         if comm is not None:
             comm.finish(grads, self.decoder_param_start())
+        return scal[0], scal[1]
+
+    def eval_losses(self, batch, eps=None, dp=None):
+        """(kl, recon) of a batch, forward only (no activations saved, no dropout): the validation pass of the fused
+        trainer.  With ``dp`` the values are this rank's share of the global-batch losses (sum over ranks = global)."""
+        self.ensure_shadow()
+        dev = self.flat.device
+        B = len(batch)
+        L = _lib.lib()
+        L.pg_train_workspace_bytes.restype = ctypes.c_size_t
+        need = L.pg_train_workspace_bytes(ctypes.byref(self.dims), self.dtype_code(), int(B), ctypes.c_long(batch.n_tokens))
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < need or ws.device != dev:
+            ws = self._ws = torch.empty(int(need * 1.25), dtype=torch.uint8, device=dev)
+        z = torch.empty(B, self.dims.Dz, device=dev)
+        scal = torch.empty(2, device=dev)
+        if dp is None:
+            dp = getattr(batch, "dp", None)
+        if eps is None:
+            eps = torch.randn(B, self.dims.Dz, device=dev)      # the reference draws eps in eval mode too (vae_model.py:233)
+        self.encoder_fwd(ws, batch, eps, dp, 0, z, None, None, scal[0:1])
+        self.decoder_fwd(ws, batch, z, dp, 0.0, 0, 0, 0, scal[1:2])
         return scal[0], scal[1]
 
     def grad_views(self, flat_grad):
@@ -425,17 +464,27 @@ class VAE(nn.Module):
     def get_collate_device(self):
         return self.device
 
-    def get_collate_fn(self):
+    def get_collate_fn(self, shard=None):
         """vae_model.py:139-149: sorts the batch by length (descending, in place, stable) and tokenises it.  The
-        result is a TokenBatch: a list of int64 tensors like the reference's, uploaded as ONE int32 matrix."""
+        result is a TokenBatch: a list of int64 tensors like the reference's, uploaded as ONE int32 matrix.
+        ``shard=(rank, world)`` (data parallelism, no counterpart in the reference): ``data`` is the GLOBAL batch; it is
+        sorted on lengths only, this rank keeps rows rank, rank+world, ... (each shard stays sorted and length-balanced,
+        SURVEY.md 8e) and tokenises and uploads just those - no rank pays for rows it discards."""
         def collate(data):
             data.sort(key=len, reverse=True)
+            n_global = len(data)
+            if shard is not None and shard[1] > 1:
+                tok_global = sum(map(len, data)) + 2 * n_global
+                data = data[shard[0]::shard[1]]
             tokens, lengths = self.vocabulary.encode_batch(data)
             dev = self.device
             t = torch.from_numpy(tokens)
             if dev.type == "cuda":
                 t = t.pin_memory().to(dev, non_blocking=True)
-            return TokenBatch(t, lengths, strings=data)
+            batch = TokenBatch(t, lengths, strings=data)
+            if shard is not None and shard[1] > 1:
+                batch.set_global(shard[0], shard[1], n_global, tok_global)
+            return batch
         return collate
 
     # ---- hot path --------------------------------------------------------------------------------------

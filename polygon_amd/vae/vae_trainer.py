@@ -16,7 +16,7 @@ import torch
 from torch.utils.data import DataLoader
 
 from polygon_amd import _lib
-from polygon_amd.parallel import GradComm, global_batch_stats, world_info
+from polygon_amd.parallel import GradComm, world_info
 from polygon_amd.utils.moses_utils import CircularBuffer, set_torch_seed_to_all_gens
 from polygon_amd.utils.utils import save_model
 from polygon_amd.vae.vae_misc import CosineAnnealingLRWithRestart, KLAnnealer
@@ -52,8 +52,8 @@ class FusedClipAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         eng = self.model._engine
         flat = eng.ensure_flat()
-        if flat.data_ptr() != self.exp_avg.data_ptr() and flat.shape != self.exp_avg.shape:
-            raise RuntimeError("model parameters changed shape under the optimiser")
+        if flat.shape != self.exp_avg.shape or flat.device != self.exp_avg.device:
+            raise RuntimeError("model parameters changed shape or device under the optimiser")
         for a, b in self.frozen:
             self.flat_grad[a:b].zero_()
         g = self.param_groups[0]
@@ -81,6 +81,54 @@ class FusedClipAdam(torch.optim.Optimizer):
         self.param_groups[0]["lr"] = float(st["lr"])
 
 
+class _Prefetcher:
+    """Bounded background iteration of a DataLoader (see VAETrainer._prefetch)."""
+    _END = object()
+
+    def __init__(self, loader, depth):
+        import queue
+        import threading
+        self.q = queue.Queue(maxsize=depth)
+        self.stop = False
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+
+        def work():
+            try:
+                if dev is not None:
+                    torch.cuda.set_device(dev)
+                for b in loader:
+                    if self.stop:
+                        return
+                    self.q.put(b)
+                self.q.put(self._END)
+            except BaseException as e:      # surfaces in the consumer
+                self.q.put(e)
+        self.t = threading.Thread(target=work, daemon=True, name="polygon-prefetch")
+        self.t.start()
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        b = self.q.get()
+        if b is self._END:
+            raise StopIteration
+        if isinstance(b, BaseException):
+            raise b
+        return b
+
+    def close(self):
+        self.stop = True
+        try:
+            while True:
+                self.q.get_nowait()
+        except Exception:
+            pass
+
+    def __del__(self):
+        self.close()
+
+
 class VAETrainer:
     def __init__(self, model, **kwargs):
         self.model = model
@@ -104,6 +152,8 @@ class VAETrainer:
         # additions (off by default = the reference's behaviour): write '<stem>_<epoch>.state.pt' (optimiser moments, step
         # count, epoch, scheduler position) next to every weight checkpoint; fit(resume_from=...) continues from one
         self.save_train_state = False
+        # batches collated ahead of the GPU step on a background thread (0 = in line, as the reference)
+        self.prefetch = 2
         self.__dict__.update(kwargs)
         self.device = self.model.device
 
@@ -115,23 +165,61 @@ class VAETrainer:
     def _save_model(self, output_path=None):
         save_model(self.model, self.model_save if output_path is None else output_path)
 
+    def _shared_seed(self):
+        """One seed all ranks agree on (rank 0's torch seed), drawn once per trainer: it keys the shuffle of the global
+        batches and the eps noise, which must be the same on every rank for the shards to form one global batch."""
+        if getattr(self, "_seed", None) is None:
+            seed = torch.tensor([torch.initial_seed() % (2 ** 31)], dtype=torch.int64)
+            rank, world = world_info()
+            if world > 1:
+                t = seed.cuda() if torch.distributed.get_backend() == "nccl" else seed
+                GradComm().broadcast(t, 0)
+                seed = t.cpu()
+            self._seed = int(seed.item())
+        return self._seed
+
     def get_dataloader(self, data, batch_size=None, collate_fn=None, shuffle=True):
         """vae_trainer.py:78-97.  ``batch_size`` is accepted and ignored exactly as the reference does (``n_batch`` is
-        used).  Under data parallelism the loader yields GLOBAL batches of n_batch * world strings, identically
-        shuffled on every rank (shared generator seed); ``_train_epoch`` takes this rank's shard."""
-        if collate_fn is None:
-            collate_fn = self.model.get_collate_fn()
+        used).  Under data parallelism the loader draws GLOBAL batches of n_batch * world strings, identically shuffled
+        on every rank (shared generator seed), and the collate keeps and tokenises only this rank's rows (sorted on
+        lengths first: VAE.get_collate_fn(shard=...))."""
         rank, world = world_info()
+        if collate_fn is None:
+            collate_fn = self.model.get_collate_fn(shard=(rank, world) if world > 1 else None)
         gen = None
         if world > 1 and shuffle:
-            seed = torch.tensor([torch.initial_seed() % (2 ** 31)], dtype=torch.int64)
-            if torch.distributed.get_backend() == "nccl":
-                seed = seed.cuda()
-            torch.distributed.broadcast(seed, 0)
-            gen = torch.Generator().manual_seed(int(seed.item()))
+            gen = torch.Generator().manual_seed(self._shared_seed())
         return DataLoader(data, batch_size=self.n_batch * world, shuffle=shuffle, num_workers=self.n_workers,
                           collate_fn=collate_fn, generator=gen,
                           worker_init_fn=set_torch_seed_to_all_gens if self.n_workers > 0 else None)
+
+    def _seed_gen(self):
+        """Host generator seeded with the shared seed: every rank draws the same per-step dropout seeds."""
+        if getattr(self, "_hgen", None) is None:
+            self._hgen = torch.Generator().manual_seed(self._shared_seed() + 1)
+        return self._hgen
+
+    def _draw_eps(self, batch):
+        """eps of vae_model.py:233 for this rank's rows.  Single process: torch.randn as the reference.  Data parallel:
+        the GLOBAL batch's eps from a device generator that every rank seeds identically, then this rank's rows
+        (rank, rank+world, ...), so that the shards form one global batch whatever the number of ranks."""
+        rank, world = world_info()
+        dev = self.model._engine.flat.device
+        dz = self.model.d_z
+        if world == 1 or batch.dp is None:
+            return torch.randn(len(batch), dz, device=dev)
+        if getattr(self, "_dgen", None) is None or self._dgen.device != dev:
+            self._dgen = torch.Generator(device=dev).manual_seed(self._shared_seed() + 2)
+        return torch.randn(batch.global_rows, dz, device=dev, generator=self._dgen)[rank::world].contiguous()
+
+    def _prefetch(self, data_loader):
+        """Iterates ``data_loader`` on a background thread, ``prefetch`` batches ahead (default 2; 0 = in line): sampling,
+        the length sort, tokenising and the pinned upload of batch i+1 overlap the GPU step of batch i (the launches are
+        asynchronous and ctypes releases the GIL).  Order and contents are exactly the loader's."""
+        depth = int(getattr(self, "prefetch", 2) or 0)
+        if depth <= 0:
+            return iter(data_loader)
+        return _Prefetcher(data_loader, depth)
 
     def get_optim_params(self):
         return (p for p in self.model.vae.parameters() if p.requires_grad)
@@ -146,32 +234,36 @@ class VAETrainer:
             model.train()
         n_batches = len(data_loader)
         kl_buf, rec_buf, loss_buf = CircularBuffer(n_batches), CircularBuffer(n_batches), CircularBuffer(n_batches)
-        fused = isinstance(optimizer, FusedClipAdam)
         rank, world = world_info()
-        comm = GradComm() if (world > 1 and fused) else None
+        fused = isinstance(optimizer, FusedClipAdam)
+        comm = GradComm() if world > 1 else None
         eng = model._engine
         debug = logging.getLogger().isEnabledFor(logging.DEBUG)
         pending = []          # device scalars read back once per epoch unless per-batch debug logging is on
         lr = 0.
-        for i, batch in enumerate(data_loader):
+        for i, batch in enumerate(self._prefetch(data_loader)):
             t_batch = time.process_time()
-            dp = None
             if world > 1:
-                inv_b, cnt = global_batch_stats(batch.lengths)
-                dp = _Dp(kl_inv_batch=inv_b, ce_count=cnt, b_mul=world, b_add=rank)
-                batch = batch.shard(rank, world)
-            if fused:
-                p_drop = float(model.d_dropout) if model.d_n_layers > 1 else 0.0
-                seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_drop > 0 else 0
+                if not isinstance(batch, TokenBatch) or batch.dp is None:
+                    raise RuntimeError("data-parallel training needs the sharding collate (VAETrainer.get_dataloader)")
+                if batch.global_rows < world:
+                    continue   # a tail with fewer strings than ranks would leave some ranks without rows: skipped on EVERY rank
+            if fused or world > 1:
                 eng.ensure_shadow()
                 b = batch if isinstance(batch, TokenBatch) else None
                 if b is None:
                     from polygon_amd.vae.vae_model import _as_batch
                     b = _as_batch(batch, model.pad, eng.flat.device)
-                kl_loss, recon_loss = eng.train_step(b, kl_weight, optimizer.flat_grad, dp=dp, p_drop=p_drop, seed=seed,
-                                                     comm=comm)
+                eps = self._draw_eps(b)
+                if optimizer is not None:
+                    p_drop = float(model.d_dropout) if model.d_n_layers > 1 else 0.0
+                    seed = int(torch.randint(0, 2 ** 62, (1,), generator=self._seed_gen()).item()) if p_drop > 0 else 0
+                    kl_loss, recon_loss = eng.train_step(b, kl_weight, optimizer.flat_grad, eps=eps, p_drop=p_drop,
+                                                         seed=seed, comm=comm)
+                    optimizer.step()
+                else:     # validation (vae_trainer.py:246-252: eval mode, fresh eps), forward only
+                    kl_loss, recon_loss = eng.eval_losses(b, eps=eps)
                 loss = kl_weight * kl_loss + recon_loss
-                optimizer.step()
             else:
                 kl_loss, recon_loss = model(batch)
                 loss = kl_weight * kl_loss + recon_loss
@@ -183,6 +275,8 @@ class VAETrainer:
             lr = optimizer.param_groups[0]['lr'] if optimizer is not None else 0.
             vals = torch.stack([kl_loss.detach().reshape(()), recon_loss.detach().reshape(()), loss.detach().reshape(())])
             if debug:
+                if comm is not None:
+                    comm.sum_scalars(vals)      # per-rank shares of the global-batch losses -> the global values
                 k, r, l = vals.tolist()
                 kl_buf.add(k); rec_buf.add(r); loss_buf.add(l)
                 logging.debug(' '.join([label, f'Batch {str(i).zfill(len(str(n_batches)))}/{n_batches}',
@@ -191,8 +285,12 @@ class VAETrainer:
             else:
                 pending.append(vals)
         if pending:
-            for k, r, l in torch.stack(pending).tolist():
+            allv = torch.stack(pending)
+            if comm is not None:
+                comm.sum_scalars(allv)          # one all-reduce per epoch
+            for k, r, l in allv.tolist():
                 kl_buf.add(k); rec_buf.add(r); loss_buf.add(l)
+        _lib.check(_lib.lib().pg_check_failure(_lib.stream_ptr()), "training epoch")   # after the epoch's sync, before anything is saved
         kl_v, rec_v, loss_v = kl_buf.mean(), rec_buf.mean(), loss_buf.mean()
         logging.info(' '.join([label, f'Time={time.process_time() - t_epoch:.2f}', f'loss={loss_v:.5f}', f'(kl={kl_v:.5f}',
                                f'recon={rec_v:.5f})', f'klw={kl_weight:.5f}', f'lr={lr:.5f}']))
@@ -257,6 +355,11 @@ class VAETrainer:
                      "----------------------"]
             with open(self.log_file, "w") as handle:
                 handle.write("\n".join(lines) + "\n")
+        _, world = world_info()
+        if world > 1:     # every rank starts from rank 0's weights (the reference has one process; nothing else syncs them)
+            flat = self.model._engine.ensure_flat()
+            GradComm().broadcast(flat, 0)
+            self.model._engine.invalidate()
         train_loader = self.get_dataloader(train_data, batch_size=batch_size, shuffle=True)
         val_loader = None if val_data is None else self.get_dataloader(val_data, batch_size=batch_size, shuffle=False)
         self._train(train_loader, val_loader, n_epoch=n_epoch, save_frequency=save_frequency, resume_from=resume_from)
