@@ -1,17 +1,27 @@
 #!/usr/bin/env python3
 """Headline benchmark: VAE training tokens/sec (BASELINE.json configs[1]: n_batch 1024, d_dropout 0.2, bf16, one MI355X;
-N>1: the same per-GPU batch data-parallel over RCCL) plus sampled molecules/sec, on synthetic GuacaMol-shaped SMILES.
+N>1: data-parallel over RCCL) plus sampled molecules/sec, on synthetic GuacaMol-shaped SMILES.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]   (N>1: launched by torch.distributed.run)
 
 A step = one pass of the training hot path over one batch already resident in HBM: encoder + decoder forward,
 hand-written BPTT, gradient all-reduce (N>1), global-norm clip and Adam (vae_trainer.py:121-138).
-Prints ONE JSON line on rank 0.
+``--scaling weak`` (default): n_batch rows PER GPU (global batch n_batch * N); ``strong``: the global batch stays n_batch
+(north_star's configs[2] definition), each rank takes 1/N of it.  The line of the scaling not selected is measured in the
+same run and reported as an extra object, so one driver run yields both.  Prints ONE JSON line on rank 0.
+
+Extra legs (all reported inside the same line): ``e2e`` = VAETrainer.fit wall clock including DataLoader, length sort,
+tokenising, pinned upload (the product's whole training path); ``sample`` = VAE.sample token matrices including the D2H
+copy, at 8192 rows per GPU plus 65 536 and 1 048 576 rows at N = 1 (configs[3]); ``strong_scaling_proxy`` (N = 1) = the
+per-rank step at the batch a rank would hold under strong scaling; ``cpu_baseline`` = the same hot path on the box's host
+cores in stock torch.nn ops (what the reference runs) and in the numpy oracle.
 """
 import argparse
 import ctypes
 import json
 import os
+import platform
+import statistics
 import sys
 import time
 
@@ -22,10 +32,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from polygon_amd import _lib  # noqa: E402
-from polygon_amd.parallel import GradComm, global_batch_stats, init_distributed  # noqa: E402
+from polygon_amd.parallel import GradComm, init_distributed  # noqa: E402
 from polygon_amd.utils.synthetic import synthetic_smiles  # noqa: E402
-from polygon_amd.vae.vae_model import VAE, TokenBatch, _Dp  # noqa: E402
-from polygon_amd.vae.vae_trainer import FusedClipAdam  # noqa: E402
+from polygon_amd.vae.vae_model import VAE  # noqa: E402
+from polygon_amd.vae.vae_trainer import FusedClipAdam, VAETrainer  # noqa: E402
 
 TRAIN_FLOP_PER_TOKEN = 26.8e6       # 4 468 992 MAC fwd x 2 flop x 3 (fwd + bwd)
 SAMPLE_FLOP_PER_MOL = 838e6         # 99 steps x 4 233 216 MAC x 2
@@ -76,17 +86,18 @@ def profile_read(which):
 
 
 def pmc_traffic(kernel, dtype):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE); None when not measured for dtype."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            t = json.load(f)
-        for name, k in t.get(dtype, {}).items():     # keys are (possibly mangled) kernel names
-            if kernel in name:
-                return float(k["hbm_bytes_per_launch"])
-        return None
-    except (OSError, ValueError, KeyError):
-        return None
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r0N_pmc_traffic.json, newest
+    round first; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE); None when not measured."""
+    for rnd in ("r02", "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % rnd)) as f:
+                t = json.load(f)
+            for name, k in t.get(dtype, {}).items():     # keys are (possibly mangled) kernel names
+                if kernel in name:
+                    return float(k["hbm_bytes_per_launch"])
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
 
 
 def roofline_recurrence(dtype):
@@ -117,30 +128,201 @@ def roofline_recurrence(dtype):
                     "LDS fragment bandwidth (every wave reads the whole 16-row tile), not by MFMA throughput: DESIGN.md 3"}
 
 
-def cpu_baseline(n_strings=1024):
-    """The CPU oracle (numpy restatement of the reference's torch CPU path), one fwd+bwd+clip+Adam step, fp32, on ONE
-    batch of the benchmark's size (bounded sample: ~5-15 s of CPU work on the GPU box's host cores)."""
-    from oracle import vae_oracle as O
+# ---- CPU baseline (SURVEY.md 8d protocol) ------------------------------------------------------------------------
+def _cpu_model():
     try:
-        import threadpoolctl
-        nthreads = max(i["num_threads"] for i in threadpoolctl.threadpool_info() or [{"num_threads": 1}])
-    except Exception:
-        nthreads = os.cpu_count()
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def _timed(fn, warm, timed, budget_s):
+    """Median wall time of fn() over `timed` runs after `warm` warm-ups; stops early (>= 2 timed runs kept) once the
+    leg has used `budget_s` seconds, so that the default bench stays within minutes on any host."""
+    t_leg = time.perf_counter()
+    for _ in range(warm):
+        fn()
+        if time.perf_counter() - t_leg > 0.4 * budget_s:
+            break
+    ts = []
+    for _ in range(timed):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+        if len(ts) >= 2 and time.perf_counter() - t_leg > budget_s:
+            break
+    return statistics.median(ts), len(ts)
+
+
+def cpu_baseline():
+    """The training step (fwd + BPTT + clip 50 + Adam, d_dropout 0.2, fp32) and the 99-step sampler on the host cores of
+    this box, in stock torch.nn ops (oracle/torch_cpu.py: what the reference's CPU path runs - nn.GRU over packed
+    sequences, F.cross_entropy, torch.multinomial, optim.Adam) and in the numpy oracle (oracle/vae_oracle.py), on a
+    BOUNDED sample of the benchmark's synthetic strings.  time.perf_counter wall clock, warm-up + timed runs, median."""
+    from oracle import torch_cpu as TC
+    from oracle import vae_oracle as O
+    cores = os.cpu_count()
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    nthreads = int(os.environ.get("OMP_NUM_THREADS", 0)) or min(cores, 16)
+    torch.set_num_threads(nthreads)
     P = O.init_params(seed=0)
-    strings = O.synthetic_smiles(n_strings, seed=1)
-    seqs = O.collate(strings)
+    n_train = 256
+    seqs = O.collate(O.synthetic_smiles(n_train, seed=1))
     ntok = sum(len(s) for s in seqs)
-    eps = np.random.default_rng(0).standard_normal((n_strings, 128)).astype(np.float32)
+    ts_ = TC.to_tensors(seqs)
+    m = TC.StockVAE(P, d_dropout=0.2).train()
+    opt = torch.optim.Adam(m.parameters(), lr=3e-4)
+    t_all, k_all = _timed(lambda: m.train_step(ts_, 0.5, opt), 3, 5, 30.0)
+    # one thread, smaller sample
+    seqs1 = O.collate(O.synthetic_smiles(64, seed=1))
+    ntok1 = sum(len(s) for s in seqs1)
+    ts1 = TC.to_tensors(seqs1)
+    torch.set_num_threads(1)
+    t_one, k_one = _timed(lambda: m.train_step(ts1, 0.5, opt), 1, 3, 10.0)
+    torch.set_num_threads(nthreads)
+    # numpy port, all BLAS threads
+    eps = np.random.default_rng(0).standard_normal((n_train, 128)).astype(np.float32)
     st = O.adam_state(P)
+
+    def np_step():
+        enc, dec = O.vae_forward(P, seqs, eps)
+        G, _ = O.vae_backward(P, enc, dec, g_kl=0.5, g_recon=1.0)
+        G, _ = O.clip_grad_norm(G, 50.0)
+        O.adam_step(P, G, st, lr=3e-4)
+    t_np, k_np = _timed(np_step, 1, 3, 12.0)
+    # sampler: 512 rows x 99 steps
+    m.eval()
+    z = torch.randn(512, 128)
+    t_s, k_s = _timed(lambda: m.sample(z, max_len=100), 1, 3, 8.0)
+    u = np.random.default_rng(1).random((99, 512), dtype=np.float32)
+    P2 = O.init_params(seed=0)
+    t_sn, k_sn = _timed(lambda: O.sample_tokens(P2, z.numpy(), u, max_len=100), 0, 2, 8.0)
+    best_train = max(ntok / t_all, ntok / t_np)
+    return {"value": best_train, "unit": "tokens/s", "cores": nthreads, "kind": "port",
+            "cpu_model": _cpu_model(), "host_cores_visible": cores,
+            "sample": "one train step (fwd+BPTT+clip+Adam, d_dropout 0.2, fp32) on %d synthetic strings = %d tokens; value = the "
+                      "faster of the two restatements; median of the timed runs after warm-up" % (n_train, ntok),
+            "train_torch_ops": {"tokens_per_s": ntok / t_all, "s_per_step": t_all, "threads": nthreads, "timed_runs": k_all,
+                                "what": "stock torch.nn ops as the reference's CPU path (oracle/torch_cpu.py)"},
+            "train_torch_ops_1thread": {"tokens_per_s": ntok1 / t_one, "s_per_step": t_one, "threads": 1, "timed_runs": k_one,
+                                        "strings": 64, "tokens": ntok1},
+            "train_numpy_port": {"tokens_per_s": ntok / t_np, "s_per_step": t_np, "threads": nthreads, "timed_runs": k_np,
+                                 "what": "oracle/vae_oracle.py (numpy fp32, BLAS threads)"},
+            "sample_torch_ops": {"molecules_per_s": 512 / t_s, "s_per_batch": t_s, "rows": 512, "max_len": 100, "timed_runs": k_s},
+            "sample_numpy_port": {"molecules_per_s": 512 / t_sn, "s_per_batch": t_sn, "rows": 512, "max_len": 100,
+                                  "timed_runs": k_sn}}
+
+
+# ---- GPU legs --------------------------------------------------------------------------------------------------
+def make_pool(model, strings, n_global, rank, world, n_pool, dev):
+    """n_pool global batches of n_global strings; each rank tokenises and keeps ONLY its shard (sharding collate)."""
+    collate = model.get_collate_fn(shard=(rank, world) if world > 1 else None)
+    pool = []
+    for i in range(n_pool):
+        b = collate(list(strings[i * n_global:(i + 1) * n_global]))
+        gen = torch.Generator(device=dev).manual_seed(1000 + i)          # the global batch's eps, same on every rank
+        eps = torch.randn(b.global_rows, model.d_z, device=dev, generator=gen)[rank::world].contiguous()
+        pool.append((b, eps))
+    return pool
+
+
+def time_steps(eng, opt, pool, comm, dropout, steps, warmup, barrier, profile=False):
+    kl_w = 0.5
+
+    def step(i):
+        b, eps = pool[i % len(pool)]
+        eng.train_step(b, kl_w, opt.flat_grad, eps=eps, p_drop=dropout, seed=1234 + i, comm=comm)
+        opt.step()
+    for i in range(warmup):
+        step(i)
+    barrier()
+    if profile:   # two event records per recurrence per step, read after the timed region
+        _lib.check(_lib.lib().pg_profile_enable(1))
+        profile_read(0), profile_read(1)
     t0 = time.perf_counter()
-    enc, dec = O.vae_forward(P, seqs, eps)
-    G, _ = O.vae_backward(P, enc, dec, g_kl=1.0, g_recon=1.0)
-    G, _ = O.clip_grad_norm(G, 50.0)
-    O.adam_step(P, G, st, lr=3e-4)
+    for i in range(steps):
+        step(warmup + i)
+    barrier()
     dt = time.perf_counter() - t0
-    return {"value": ntok / dt, "unit": "tokens/s", "cores": int(min(nthreads, os.cpu_count())), "kind": "port",
-            "sample": "1 train step (fwd+BPTT+clip+Adam) of oracle/vae_oracle.py (numpy fp32) on %d synthetic strings, "
-                      "%d tokens, %.1f s wall" % (n_strings, ntok, dt)}
+    if profile:
+        _lib.check(_lib.lib().pg_profile_enable(0))
+    tokens = sum(pool[(warmup + i) % len(pool)][0].global_tokens for i in range(steps))
+    return dt, tokens
+
+
+def max_over_ranks(dt, world, dev):
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def e2e_leg(args, dev, rank, world, barrier):
+    """VAETrainer.fit over a synthetic slice: wall clock of the PRODUCT path including the DataLoader's shuffle, the
+    length sort, tokenising, the pinned upload and the per-epoch loss read-back (vae_trainer.py:78-97,121-144)."""
+    n_global = args.n_batch * world if args.scaling == "weak" else args.n_batch
+    n_batches = 128 if world == 1 else 64
+    strings = synthetic_smiles(n_batches * n_global, seed=7)
+    ntok = sum(map(len, strings)) + 2 * len(strings)
+    torch.manual_seed(0)
+    model = VAE(d_dropout=args.dropout, compute_dtype=args.dtype).to(dev)
+    kw = dict(n_batch=n_global // world, n_epoch=1, kl_start=0, kl_w_start=0.5, model_save=None, log_file=None)
+    VAETrainer(model, **kw).fit(list(strings[:8 * n_global]))                      # warm-up (allocator, pinned pool)
+    # host work per batch, in line (what the background thread hides): loader + sort + tokenise + pin + upload
+    tr = VAETrainer(model, **kw)
+    loader = tr.get_dataloader(list(strings[:16 * n_global]), shuffle=True)
+    t0 = time.perf_counter()
+    nb = sum(1 for _ in loader)
+    torch.cuda.synchronize()
+    host_ms = (time.perf_counter() - t0) / nb * 1e3
+    out = {}
+    for label, prefetch in (("prefetch2", 2), ("inline", 0)):
+        tr = VAETrainer(model, prefetch=prefetch, **kw)
+        barrier()
+        t0 = time.perf_counter()
+        tr.fit(list(strings))
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+        out[label] = {"tokens_per_s": ntok / dt, "s_per_epoch": dt, "ms_per_batch": dt / n_batches * 1e3}
+    return {"metric": "e2e_fit_tokens_per_sec", "value": out["prefetch2"]["tokens_per_s"], "unit": "tokens/s",
+            "strings": len(strings), "tokens": ntok, "batches": n_batches, "global_batch": n_global,
+            "host_ms_per_batch_inline": host_ms, "with_background_collate": out["prefetch2"], "collate_in_line": out["inline"],
+            "what": "VAETrainer.fit, 1 epoch, wall clock incl. DataLoader shuffle, length sort, tokenise, pinned upload, "
+                    "fused step, epoch-end loss read-back; each rank tokenises only its shard"}
+
+
+def sample_leg(model, n, rank, world, dev, barrier, reps=3):
+    """n rows per GPU, max_len 100: token matrix + end positions INCLUDING the D2H copy (SURVEY.md 8d metric 2)."""
+    z = torch.randn(n, model.d_z, device=dev)
+
+    def once(seed):
+        tok, ep = model.sample_tokens(n, max_len=100, z=z, seed=seed, row_offset=rank * n)
+        return tok.cpu(), ep.cpu()
+    once(1)
+    barrier()
+    t1 = time.perf_counter()
+    for r in range(reps):
+        once(2 + r)
+    barrier()
+    ds = max_over_ranks(time.perf_counter() - t1, world, dev)
+    # device-only time of the same call, for the split
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    model.sample_tokens(n, max_len=100, z=z, seed=9, row_offset=rank * n)
+    torch.cuda.synchronize()
+    dev_ms = (time.perf_counter() - t2) * 1e3
+    mol_s = reps * n * world / ds
+    return {"value": mol_s, "unit": "molecules/s", "n_per_gpu": n, "max_len": 100, "ms_per_batch": ds / reps * 1e3,
+            "ms_per_batch_device_only": dev_ms, "includes_d2h": True,
+            "tflops": mol_s * SAMPLE_FLOP_PER_MOL / 1e12}
 
 
 def main():
@@ -149,11 +331,15 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--n_batch", type=int, default=1024, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--n_batch", type=int, default=1024, help="batch per GPU (weak) / global batch (strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--dropout", type=float, default=0.2)
     ap.add_argument("--sample_n", type=int, default=8192, help="molecules per GPU in the sampling leg (0 = skip)")
+    ap.add_argument("--sample_extra", default="65536,1048576", help="more row counts for the sampling leg at N = 1")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_roofline", action="store_true")
+    ap.add_argument("--no_e2e", action="store_true")
+    ap.add_argument("--no_other_scaling", action="store_true")
     args = ap.parse_args()
 
     rank, world, local = init_distributed()
@@ -166,99 +352,87 @@ def main():
     opt = FusedClipAdam(model, lr=3e-4, clip_grad=50)
     eng = model._engine
     eng.ensure_shadow()
-
-    # synthetic global batches, identical on every rank; each rank keeps its shard resident in HBM
-    n_pool = 8
-    Bg = args.n_batch * world
-    strings = synthetic_smiles(n_pool * Bg, seed=20250310)
-    collate = model.get_collate_fn()
-    pool = []
-    for i in range(n_pool):
-        gb = collate(strings[i * Bg:(i + 1) * Bg])
-        dp = None
-        tokens_global = int(gb.lengths.sum())
-        if world > 1:
-            inv_b, cnt = global_batch_stats(gb.lengths)
-            dp = _Dp(kl_inv_batch=inv_b, ce_count=cnt, b_mul=world, b_add=rank)
-            gb = gb.shard(rank, world)
-        eps = torch.randn(len(gb), model.d_z, device=dev)
-        pool.append((gb, dp, eps, tokens_global))
     comm = GradComm() if world > 1 else None
-    kl_w = 0.5
-
-    def step(i):
-        b, dp, eps, _ = pool[i % n_pool]
-        eng.train_step(b, kl_w, opt.flat_grad, eps=eps, dp=dp, p_drop=args.dropout, seed=1234 + i, comm=comm)
-        opt.step()
+    if comm is not None:
+        comm.broadcast(eng.flat, 0)
+        eng.invalidate()
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    barrier()
-    if rank == 0 and not args.no_roofline:   # two event records per recurrence per step, read after the timed region
-        _lib.check(_lib.lib().pg_profile_enable(1))
-        profile_read(0), profile_read(1)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    barrier()
-    dt = time.perf_counter() - t0
-    roofline = None
-    if rank == 0 and not args.no_roofline:
-        _lib.check(_lib.lib().pg_profile_enable(0))
-        roofline = roofline_recurrence(args.dtype)
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    tokens = sum(pool[(args.warmup + i) % n_pool][3] for i in range(args.steps))
+    n_pool = 8
+
+    def run_scaling(mode, profile):
+        n_global = args.n_batch * world if mode == "weak" else args.n_batch
+        strings = synthetic_smiles(n_pool * n_global, seed=20250310)
+        pool = make_pool(model, strings, n_global, rank, world, n_pool, dev)
+        dt, tokens = time_steps(eng, opt, pool, comm, args.dropout, args.steps, args.warmup, barrier, profile)
+        return max_over_ranks(dt, world, dev), tokens, n_global
+
+    profile = rank == 0 and not args.no_roofline
+    dt, tokens, n_global = run_scaling(args.scaling, profile)
+    roofline = roofline_recurrence(args.dtype) if profile else None
     tok_per_s = tokens / dt
     kl, recon = eng._small[2].tolist()
+    other = None
+    if world > 1 and not args.no_other_scaling:
+        mode = "strong" if args.scaling == "weak" else "weak"
+        dt2, tokens2, ng2 = run_scaling(mode, False)
+        other = {"scaling": mode, "value": tokens2 / dt2, "unit": "tokens/s", "ms_per_step": dt2 / args.steps * 1e3,
+                 "global_batch": ng2, "rows_per_gpu": ng2 // world}
+    proxy = None
+    if world == 1:   # the step a rank would run under strong scaling of the 1024-row global batch (no all-reduce)
+        proxy = {}
+        for nb in (512, 256, 128):
+            strings = synthetic_smiles(n_pool * nb, seed=20250310)
+            pool = make_pool(model, strings, nb, 0, 1, n_pool, dev)
+            d, t = time_steps(eng, opt, pool, None, args.dropout, 20, 3, barrier)
+            proxy["n_batch_%d" % nb] = {"ms_per_step": d / 20 * 1e3, "tokens_per_s": t / d}
 
-    # ---- sampling leg (cfg4): per-GPU shard, no collective ------------------------------------------------
+    e2e = None
+    if not args.no_e2e:
+        e2e = e2e_leg(args, dev, rank, world, barrier)
+
+    # ---- sampling leg (configs[3]): per-GPU shard, no collective during decode --------------------------------
     sample = None
     if args.sample_n > 0:
         model.eval()
-        z = torch.randn(args.sample_n, model.d_z, device=dev)
-        model.sample_tokens(args.sample_n, max_len=100, z=z, seed=1, row_offset=rank * args.sample_n)
-        barrier()
-        t1 = time.perf_counter()
-        reps = 3
-        for r in range(reps):
-            tok, ep = model.sample_tokens(args.sample_n, max_len=100, z=z, seed=2 + r, row_offset=rank * args.sample_n)
-        barrier()
-        ds = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([ds], device=dev, dtype=torch.float64)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-            ds = float(t.item())
-        mol_s = reps * args.sample_n * world / ds
-        sample = {"metric": "sampled_molecules_per_sec", "value": mol_s, "unit": "molecules/s", "n_per_gpu": args.sample_n,
-                  "max_len": 100, "ms_per_batch": ds / reps * 1e3,
-                  "kernel": "dec_sample_persist_kernel (the whole decode loop of a batch in one group-persistent launch: "
-                            "3 GRU layers + vocab projection + softmax + inverse-CDF draw)" if args.dtype == "bf16" else
-                            "gru_fwd2_kernel x3 + sample_head_kernel per step",
-                  "tflops": mol_s * SAMPLE_FLOP_PER_MOL / 1e12,
-                  "frac_of_mfma_peak": mol_s * SAMPLE_FLOP_PER_MOL / 1e12 / (PEAK[args.dtype] * world)}
+        sample = sample_leg(model, args.sample_n, rank, world, dev, barrier)
+        sample.update({"metric": "sampled_molecules_per_sec",
+                       "kernel": "dec_sample_persist_kernel (the whole decode loop of up to 16384 rows in one group-persistent "
+                                 "launch: 3 GRU layers + vocab projection + softmax + inverse-CDF draw)" if args.dtype == "bf16"
+                                 else "gru_fwd2_kernel x3 + sample_head_kernel per step",
+                       "frac_of_mfma_peak": sample["value"] * SAMPLE_FLOP_PER_MOL / 1e12 / (PEAK[args.dtype] * world)})
+        if world == 1 and args.sample_extra:
+            sample["more_rows"] = {}
+            for n in [int(x) for x in args.sample_extra.split(",") if x]:
+                s = sample_leg(model, n, 0, 1, dev, barrier, reps=2 if n > 100000 else 3)
+                sample["more_rows"]["n_%d" % n] = {k: s[k] for k in ("value", "ms_per_batch", "ms_per_batch_device_only")}
 
     if rank == 0:
         out = {
             "metric": "vae_train_tokens_per_sec", "value": tok_per_s, "unit": "tokens/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "configs[1]: MOSES-default SMILES VAE (GRU enc 256, 3xGRU dec 512, d_z 128, vocab 51) "
-                                   "pretraining step, n_batch %d per GPU, d_dropout %.2f, %s, synthetic GuacaMol-shaped "
-                                   "strings (mean 49 tokens), fwd+BPTT+clip+Adam" % (args.n_batch, args.dropout, args.dtype),
-                       "global_batch": Bg, "parallelism": "dp%d" % world},
+                                   "pretraining step, %s, d_dropout %.2f, %s, synthetic GuacaMol-shaped strings (mean 49 "
+                                   "tokens), fwd+BPTT+clip+Adam" % (
+                                       "n_batch %d per GPU" % args.n_batch if args.scaling == "weak" else
+                                       "global batch %d split over the GPUs" % args.n_batch, args.dropout, args.dtype),
+                       "global_batch": n_global, "parallelism": "dp%d" % world},
             "train_tflops": tok_per_s * TRAIN_FLOP_PER_TOKEN / 1e12,
             "train_frac_of_mfma_peak": tok_per_s * TRAIN_FLOP_PER_TOKEN / 1e12 / (PEAK[args.dtype] * world),
             "last_losses": {"kl": kl, "recon": recon},
             "sample": sample,
         }
+        if other is not None:
+            out["other_scaling"] = other
+        if proxy is not None:
+            out["strong_scaling_proxy"] = proxy
+        if e2e is not None:
+            out["e2e"] = e2e
         if roofline is not None:
             out["roofline"] = roofline
             out["roofline"]["single_cell_microbench"] = step_kernel_microbench(args.dtype, args.n_batch, 512)

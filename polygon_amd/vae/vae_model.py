@@ -614,10 +614,14 @@ class VAE(nn.Module):
                 raise RuntimeError("n_batch (%d) must equal z.shape[0] (%d)" % (n_batch, z.shape[0]))
             L = _lib.lib()
             L.pg_sample_workspace_bytes.restype = ctypes.c_size_t
-            nbytes = L.pg_sample_workspace_bytes(ctypes.byref(eng.dims), eng.dtype_code(), int(n_batch))
+            CH = 65536                 # rows per library call: bounds the workspace (~22 KB per row) whatever n_batch is
+            rows = min(n_batch, CH)
+            nbytes = L.pg_sample_workspace_bytes(ctypes.byref(eng.dims), eng.dtype_code(), int(rows))
             if nbytes == 0:
                 raise _lib.PolygonHipError("pg_sample_workspace_bytes: " + L.pg_last_error().decode())
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            ws = getattr(eng, "_sample_ws", None)      # kept between calls (generate samples 8192 rows every epoch)
+            if ws is None or ws.numel() < nbytes or ws.device != dev:
+                ws = eng._sample_ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             tokens = torch.empty(n_batch, max_len, dtype=torch.uint8, device=dev)
             end_pads = torch.empty(n_batch, dtype=torch.int32, device=dev)
             if uniforms is not None:
@@ -626,19 +630,25 @@ class VAE(nn.Module):
                     raise RuntimeError("uniforms must have shape [max_len-1, n_batch]")
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            args = [ctypes.byref(eng.dims), eng.dtype_code(), _lib.ptr(eng.flat), _lib.ptr(eng.shadow), _lib.ptr(ws),
-                    ctypes.c_size_t(nbytes), int(n_batch), int(max_len), _lib.ptr(z), _lib.ptr(uniforms),
-                    ctypes.c_uint64(seed), ctypes.c_long(int(row_offset)), ctypes.c_float(float(temp)),
-                    int(bool(multinomial)), _lib.ptr(tokens), _lib.ptr(end_pads)]
-            if forced is None and not return_probs:
-                _lib.check(L.pg_sample(*args, _lib.stream_ptr()), "pg_sample")
-                return tokens, end_pads
+            hooks = forced is not None or return_probs
+            if hooks and n_batch > CH:
+                raise RuntimeError("the parity hooks (forced / return_probs) take at most %d rows" % CH)
             probs = torch.zeros(max_len - 1, n_batch, 64, device=dev) if return_probs else None
             if forced is not None:
                 forced = forced.to(dev, torch.uint8).contiguous()
                 if tuple(forced.shape) != (n_batch, max_len):
                     raise RuntimeError("forced must have shape [n_batch, max_len]")
-            _lib.check(L.pg_sample_forced(*args, _lib.ptr(forced), _lib.ptr(probs), _lib.stream_ptr()), "pg_sample_forced")
+            for r0 in range(0, n_batch, CH):
+                m = min(CH, n_batch - r0)
+                u = None if uniforms is None else (uniforms if m == n_batch else uniforms[:, r0:r0 + m].contiguous())
+                args = [ctypes.byref(eng.dims), eng.dtype_code(), _lib.ptr(eng.flat), _lib.ptr(eng.shadow), _lib.ptr(ws),
+                        ctypes.c_size_t(ws.numel()), int(m), int(max_len), _lib.ptr(z[r0:r0 + m]), _lib.ptr(u),
+                        ctypes.c_uint64(seed), ctypes.c_long(int(row_offset) + r0), ctypes.c_float(float(temp)),
+                        int(bool(multinomial)), _lib.ptr(tokens[r0:r0 + m]), _lib.ptr(end_pads[r0:r0 + m])]
+                if hooks:
+                    _lib.check(L.pg_sample_forced(*args, _lib.ptr(forced), _lib.ptr(probs), _lib.stream_ptr()), "pg_sample_forced")
+                else:
+                    _lib.check(L.pg_sample(*args, _lib.stream_ptr()), "pg_sample")
             return (tokens, end_pads, probs) if return_probs else (tokens, end_pads)
 
     def sample(self, n_batch, max_len=100, z=None, temp=1.0, multinomial=True):

@@ -152,8 +152,11 @@ class VAETrainer:
         # additions (off by default = the reference's behaviour): write '<stem>_<epoch>.state.pt' (optimiser moments, step
         # count, epoch, scheduler position) next to every weight checkpoint; fit(resume_from=...) continues from one
         self.save_train_state = False
-        # batches collated ahead of the GPU step on a background thread (0 = in line, as the reference)
-        self.prefetch = 2
+        # batches collated ahead of the GPU step on a background thread; 0 = in line, as the reference.  Measured on the
+        # MI355X box (bench.py e2e leg, 128 batches of 1024): in-line collate costs 0.47 ms per batch and fit() runs at 98 %
+        # of the resident-batch rate; the background thread competes with the launching thread for the GIL and fit() drops
+        # to 90 % - so the default is in line.  Worth turning on only where the host is slow (collate >= the GPU step).
+        self.prefetch = 0
         self.__dict__.update(kwargs)
         self.device = self.model.device
 
@@ -216,7 +219,7 @@ class VAETrainer:
         """Iterates ``data_loader`` on a background thread, ``prefetch`` batches ahead (default 2; 0 = in line): sampling,
         the length sort, tokenising and the pinned upload of batch i+1 overlap the GPU step of batch i (the launches are
         asynchronous and ctypes releases the GIL).  Order and contents are exactly the loader's."""
-        depth = int(getattr(self, "prefetch", 2) or 0)
+        depth = int(getattr(self, "prefetch", 0) or 0)
         if depth <= 0:
             return iter(data_loader)
         return _Prefetcher(data_loader, depth)

@@ -115,3 +115,31 @@ def test_sampler_matches_reference(golden_dir, tag, dims, seed):
     x, ep = O.sample_tokens(P, g["z"].astype(np.float64), None, max_len=max_len, temp=float(g["temp"]),
                             multinomial=False)
     assert O.tokens_to_strings(x, ep) == [str(s) for s in g["strings_argmax"]]
+
+
+def test_stock_torch_cpu_baseline_matches_oracle():
+    """oracle/torch_cpu.py (the CPU baseline bench.py times: the hot path in stock torch.nn ops, as the reference runs it)
+    against the numpy oracle: losses, gradient norm and one clip+Adam step."""
+    import torch
+    from oracle import torch_cpu as TC
+    dims = dict(Hq=32, Dz=16, Hd=64, L=3)
+    P = O.init_params(seed=5, **dims)
+    strings = O.synthetic_smiles(12, seed=2) + ["", "C"]
+    seqs = O.collate(strings)
+    eps = np.random.default_rng(0).standard_normal((len(seqs), dims["Dz"])).astype(np.float32)
+    m = TC.StockVAE(P)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=3e-4)
+    kl, rec, gn = m.train_step(TC.to_tensors(seqs), 0.5, opt, eps=torch.from_numpy(eps))
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    enc, dec = O.vae_forward(P64, seqs, eps.astype(np.float64))
+    G, _ = O.vae_backward(P64, enc, dec, g_kl=0.5, g_recon=1.0)
+    Gc, total = O.clip_grad_norm(G, 50.0)
+    assert abs(kl - enc["kl"]) <= 1e-4 * abs(enc["kl"]) and abs(rec - dec["recon"]) <= 1e-5 * abs(dec["recon"])
+    assert abs(gn - total) <= 1e-4 * total
+    st = O.adam_state(P64)
+    P1 = O.adam_step(dict(P64), Gc, st, lr=3e-4)
+    for k, p in m.named_parameters():
+        assert np.abs(p.detach().numpy() - P1[k]).max() <= 2e-5, k
+    x, end = m.sample(torch.zeros(3, dims["Dz"]), max_len=12)
+    assert x.shape == (3, 12) and (x[:, 0] == O.BOS).all() and (end <= 12).all()
