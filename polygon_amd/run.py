@@ -118,6 +118,9 @@ def generate_parser(sub):
     r.add_argument('--save_frequency', type=int, default=5)
     r.add_argument('--save_payloads', action='store_true', default=False)
     r.add_argument('--save_individual_scores', action='store_true', default=False)
+    r.add_argument('--batched_scoring', action='store_true', default=False,
+                   help='(polygon_amd) LatentDistance raw scores from one batched encoder pass per generation and '
+                        'score_list over --n_jobs host threads; same scores as the one-molecule-at-a-time loop')
     _trainer_arguments(p.add_argument_group("Optional Training Parameters"), kl_w_start=0)
     _global_arguments(p)
     return p
@@ -157,7 +160,9 @@ def train_main(args):
 
 def generate_main(args):
     """run.py:622-718; scoring comes from the reference's own host modules."""
-    device = torch.device(args.device)
+    rank, world, local = init_distributed()
+    device = torch.device(args.device if world == 1 else "cuda:%d" % local)
+    args.device = str(device)
     if device.type.startswith("cuda"):
         torch.cuda.set_device(device.index or 0)
     if args.seed:                                     # seed 0 means "no seed", as in the reference (run.py:636)
@@ -168,8 +173,13 @@ def generate_main(args):
         raise ImportError("`generate` scores molecules with the reference's host stack (polygon.utils + RDKit), which "
                           "stays on the CPU unchanged; install the reference package next to polygon_amd") from e
     scorers = None
+    # latent_distance rows make the reference build a VAE "on the cpu" and call encode() one molecule at a time
+    # (utils.py:285-300): HostScoringVAE keeps that model on the MI355X and hands CPU tensors back to the host scorer
+    from polygon_amd.vae.scoring import HostScoringVAE
+    HostScoringVAE.compute_device = str(device)
     built = build_scoring_function(args.scoring_definition, args.encoding, args.cell_line_model, args.fscores,
-                                   opti=args.opti, return_individual=bool(args.save_individual_scores), vae_model=VAE)
+                                   opti=args.opti, return_individual=bool(args.save_individual_scores),
+                                   vae_model=HostScoringVAE)
     if args.save_individual_scores:
         scorers, scoring_function = built
     else:
@@ -187,15 +197,17 @@ def generate_main(args):
             logging.error(f'Did not understand starting population: {args.starting_population}')
             raise ValueError()
     generator = SmilesVaeMoleculeGenerator(model=model, max_len=args.max_len, device=device, out_dir=args.outF,
-                                           lr=args.lr_start)
+                                           lr=args.lr_start, n_jobs=args.n_jobs,
+                                           batched_scoring=bool(getattr(args, "batched_scoring", False)))
     molecules = generator.optimise(objective=scoring_function, start_population=starting_population,
                                    n_epochs=args.n_epochs, mols_to_sample=args.mols_to_sample, keep_top=args.keep_top,
                                    optimize_batch_size=args.optimize_batch_size,
                                    optimize_n_epochs=args.optimize_n_epochs, pretrain_n_epochs=args.pretrain_n_epochs,
                                    ind_scorers=scorers, save_payloads=args.save_payloads,
                                    save_frequency=args.save_frequency)
-    with open(os.path.join(args.outF, "GDM_final_molecules.txt"), 'w') as handle:
-        handle.writelines("{}\n".format(m.smiles) for m in molecules)
+    if rank == 0:
+        with open(os.path.join(args.outF, "GDM_final_molecules.txt"), 'w') as handle:
+            handle.writelines("{}\n".format(m.smiles) for m in molecules)
     logging.getLogger().info("Molecule Generation Complete")
 
 

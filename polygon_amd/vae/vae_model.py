@@ -574,7 +574,7 @@ class VAE(nn.Module):
         for a in range(0, n, batch_size):
             idx = order[a:a + batch_size]
             batch = collate([smiles_list[i] for i in idx])                            # already sorted: order is kept
-            mu = self.encode(batch)
+            mu = VAE.encode(self, batch)            # the device-side encode, whatever a subclass hands its callers
             out[torch.tensor(idx, device=out.device)] = mu
         return out
 
@@ -592,7 +592,7 @@ class VAE(nn.Module):
             noise_vec = np.random.normal(0, 1, size=z.shape)
             noise_vec = noise_vec / np.linalg.norm(noise_vec)
             if constant_norm:
-                return z + (noise_norm * noise_vec)
+                return z + (noise_norm * noise_vec)      # tensor + float64 ndarray, exactly as the reference
             noise_amp = np.random.uniform(0, noise_norm, size=(z.shape[0], 1))
             return z + torch.tensor(noise_amp * noise_vec, dtype=z.dtype)
         return z
@@ -655,6 +655,50 @@ class VAE(nn.Module):
         """vae_model.py:300-358 -> list of strings (no early exit; specials mid-stream rendered literally)."""
         tokens, end_pads = self.sample_tokens(n_batch, max_len=max_len, z=z, temp=temp, multinomial=multinomial)
         return self.vocabulary.decode_batch(tokens.cpu().numpy(), end_pads.cpu().numpy())
+
+    def sample_sharded(self, n_batch, max_len=100, temp=1.0, multinomial=True, seed=None, group=None):
+        """``sample`` over the ranks of a torch.distributed job (no counterpart in the reference): the rows
+        are split contiguously, rank r decodes rows [r*q, (r+1)*q) with no collective during the decode, and ONE final
+        all-gather of the uint8 token matrix [n, max_len] + end positions hands every rank the whole list.  The prior
+        draws z and the sampler's Philox stream are keyed by (seed, global row), so the strings do not depend on the
+        number of ranks.  ``seed`` None: rank 0 draws one and broadcasts it.  One process: same result, no collective."""
+        import torch.distributed as dist
+        from polygon_amd.parallel import GradComm, world_info
+        rank, world = world_info()
+        dev = self.device
+        if seed is None:
+            t = torch.randint(0, 2 ** 62, (1,))
+            if world > 1:
+                comm = GradComm(group)
+                t = t.to(dev) if not comm.staged else t
+                comm.broadcast(t, 0)
+            seed = int(t.item())
+        z_all = torch.randn(n_batch, self.q_mu.out_features, device=dev,
+                            generator=torch.Generator(device=dev).manual_seed(seed % (2 ** 63 - 1)))
+        q = (n_batch + world - 1) // world
+        r0, r1 = min(rank * q, n_batch), min((rank + 1) * q, n_batch)
+        tok = torch.full((q, max_len), self.pad, dtype=torch.uint8, device=dev)
+        ep = torch.zeros(q, dtype=torch.int32, device=dev)
+        if r1 > r0:
+            t, e = self.sample_tokens(r1 - r0, max_len=max_len, z=z_all[r0:r1], temp=temp, multinomial=multinomial,
+                                      seed=seed, row_offset=r0)
+            tok[:r1 - r0], ep[:r1 - r0] = t, e
+        if world > 1:
+            comm = GradComm(group)
+            if comm.staged:      # gloo: through the host
+                tok_h, ep_h = tok.cpu(), ep.cpu()
+                toks = [torch.empty_like(tok_h) for _ in range(world)]
+                eps_ = [torch.empty_like(ep_h) for _ in range(world)]
+                dist.all_gather(toks, tok_h, group=group)
+                dist.all_gather(eps_, ep_h, group=group)
+                tok_all, ep_all = torch.cat(toks), torch.cat(eps_)
+            else:                # RCCL: one all-gather per tensor on the device, then one D2H copy
+                tok_all = torch.empty(world * q, max_len, dtype=torch.uint8, device=dev)
+                ep_all = torch.empty(world * q, dtype=torch.int32, device=dev)
+                dist.all_gather_into_tensor(tok_all, tok, group=group)
+                dist.all_gather_into_tensor(ep_all, ep, group=group)
+            tok, ep = tok_all, ep_all
+        return self.vocabulary.decode_batch(tok[:n_batch].cpu().numpy(), ep[:n_batch].cpu().numpy())
 
 
 def _packed_index(lens):

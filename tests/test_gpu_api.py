@@ -1,0 +1,214 @@
+"""The rest of the reference's VAE API on the device (SURVEY.md 8 rows a11, a4, f2/f4, configs[4]): decode(z, x),
+get_latent_space_from_smiles, perturb_z, freeze_embeddings, a data-derived vocabulary with V != 51 through the kernels,
+the host-scoring glue of `generate` (the reference's LatentDistance calling sequence against the MI355X model, one molecule
+at a time and batched), sharded sampling, and the generate loop at configs[4]'s real sizes with a stub host scorer."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vae_oracle as O
+from tests.helpers import REAL, TINY, build_model, canon_named, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_decode_teacher_forced_matches_oracle(dt):
+    """VAE.decode(z, x) (vae_model.py:183-197): argmax of the teacher-forced logits, cut at the first eos."""
+    model, P = build_model(REAL, 6, dt, eos_bias=1.5)
+    model.eval()
+    strings = list(O.synthetic_smiles(40, seed=12)) + ["C", ""]
+    batch = model.get_collate_fn()(list(strings))
+    seqs = O.collate(strings)
+    z = np.random.default_rng(2).standard_normal((len(strings), REAL["Dz"])).astype(np.float32)
+    got = model.decode(torch.from_numpy(z).cuda(), batch)
+    want = O.decode_teacher_forced(P, seqs, z.astype(np.float64))
+    if dt == "fp32":
+        assert got == want
+    else:       # bf16 logits may flip an argmax between two near-equal entries: nearly all rows identical
+        assert np.mean([a == b for a, b in zip(got, want)]) >= 0.9
+    # decode(z) without x samples (vae_model.py:198-199): one string per row
+    out = model.decode(torch.from_numpy(z[:5]).cuda())
+    assert len(out) == 5 and all(isinstance(s, str) for s in out)
+
+
+def test_get_latent_space_from_smiles_and_perturb_z():
+    """vae_model.py:202-214 (z of ONE string = mu + exp(logvar/2) eps) and :287-298 (host numpy noise)."""
+    model, P = build_model(REAL, 7, "fp32")
+    model.eval()
+    eps = np.random.default_rng(0).standard_normal((1, REAL["Dz"])).astype(np.float32)
+    model._eps_override = torch.from_numpy(eps).cuda()
+    z = model.get_latent_space_from_smiles("CCOc1ccccc1")
+    enc = O.encoder_forward(P, O.collate(["CCOc1ccccc1"]), eps.astype(np.float64), keep=False)
+    assert z.shape == (REAL["Dz"],) and rel_err(z, enc["z"][0]) <= 1e-3
+    model._eps_override = None
+    zc = z.detach().cpu().reshape(1, -1)
+    assert torch.equal(model.perturb_z(zc, 0.0), zc)
+    np.random.seed(0)
+    p = model.perturb_z(zc, 0.5, constant_norm=True)
+    assert abs(float(torch.as_tensor(p - zc).norm()) - 0.5) <= 1e-5          # noise of exactly the requested norm
+    p = model.perturb_z(zc, 0.5)
+    assert 0.0 <= float(torch.as_tensor(p - zc).norm()) <= 0.5 + 1e-6
+
+
+def test_freeze_embeddings_zeroes_the_embedding_update():
+    """freeze_embeddings=True (vae_model.py:61-62): x_emb gets no gradient through autograd and no update from the fused
+    optimiser, everything else trains."""
+    from polygon_amd.vae.vae_trainer import FusedClipAdam
+    model, _ = build_model(TINY, 1, "fp32", freeze_embeddings=True)
+    assert not model.x_emb.weight.requires_grad
+    model.train()
+    batch = model.get_collate_fn()(list(O.synthetic_smiles(16, seed=1)))
+    kl, rec = model(batch)
+    (kl + rec).backward()
+    assert model.x_emb.weight.grad is None
+    assert all(p.grad is not None and p.grad.abs().sum() > 0 for n, p in canon_named(model).items() if n != "x_emb.weight")
+    before = model.x_emb.weight.detach().clone()
+    w_before = model.decoder_fc.weight.detach().clone()
+    opt = FusedClipAdam(model, lr=1e-2)
+    model._engine.train_step(batch, 0.5, opt.flat_grad)
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(model.x_emb.weight.detach(), before)
+    assert not torch.equal(model.decoder_fc.weight.detach(), w_before)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_data_derived_vocabulary_through_the_kernels(dt):
+    """OneHotVocab.from_data (vae_model.py:11-12): V = 9 + 4 specials, E = V, other special ids - forward, gradients and
+    the sampler run on that vocabulary and agree with the oracle restated over the same parameters."""
+    from polygon_amd.vae.vae_model import VAE, get_vocabulary
+    data = ["CCO", "c1ccccc1N", "C(=O)O", "CN", "CC(C)C"]
+    vocab = get_vocabulary(data)
+    V = len(vocab)
+    assert V == len(set("".join(data))) + 4 and V != 51
+    dims = dict(Hq=64, Dz=32, Hd=128, L=3)
+    torch.manual_seed(3)
+    model = VAE(vocabulary=vocab, q_d_h=64, d_z=32, d_d_h=128, compute_dtype=dt).cuda()
+    assert (model.bos, model.eos, model.pad, model.unk) == (V - 4, V - 3, V - 2, V - 1)
+    model.eval()
+    P = {k: p.detach().cpu().double().numpy() for k, p in canon_named(model).items()}
+    strings = ["CCO", "CCN(C)C", "c1ccccc1", "C", "", "CCZ"]          # 'Z' is not in the data: unk
+    batch = model.get_collate_fn()(list(strings))
+    # an oracle over THIS vocabulary: same arithmetic, ids from the product's (bit-exact, CPU-tested) tokeniser
+    ids = [np.asarray(vocab.string2ids(s, add_bos=True, add_eos=True)) for s in sorted(strings, key=len, reverse=True)]
+    eps = np.random.default_rng(1).standard_normal((len(strings), 32)).astype(np.float32)
+    model._eps_override = torch.from_numpy(eps).cuda()
+    old = (O.PAD, O.EOS, O.BOS)
+    O.PAD, O.EOS, O.BOS = model.pad, model.eos, model.bos
+    try:
+        enc, dec = O.vae_forward(P, ids, eps.astype(np.float64))
+        G, _ = O.vae_backward(P, enc, dec, g_kl=0.5, g_recon=1.0)
+        kl, rec = model(batch)
+        (0.5 * kl + rec).backward()
+        tol = 1e-3 if dt == "fp32" else 2e-2
+        assert abs(kl.item() - enc["kl"]) <= tol * abs(enc["kl"]) and abs(rec.item() - dec["recon"]) <= tol * abs(dec["recon"])
+        for k, p in canon_named(model).items():
+            assert rel_err(p.grad, G[k]) <= 1e-2, k
+        z = np.random.default_rng(2).standard_normal((4, 32)).astype(np.float32)
+        x, ep = O.sample_tokens(P, z.astype(np.float64), None, max_len=15, multinomial=False)
+        tok, e = model.sample_tokens(4, max_len=15, z=torch.from_numpy(z), multinomial=False)
+        if dt == "fp32":
+            assert (tok.cpu().numpy() == x).all() and (e.cpu().numpy() == ep).all()
+        assert (tok.cpu().numpy() < V).all()
+    finally:
+        O.PAD, O.EOS, O.BOS = old
+
+
+class _RefLikeLatentDistance:
+    """The calling sequence of the reference's LatentDistance (custom_scoring_fcn.py:149-178), restated for the test:
+    collate the targets, encode -> z_targets; per molecule collate([s]) -> encode -> host torch.norm -> .numpy()."""
+
+    def __init__(self, smiles_targets, model, n_top=None, agg="mean"):
+        self.model = model
+        self.collate_fn = model.get_collate_fn()
+        self.z_targets = model.encode(self.collate_fn(list(smiles_targets)))
+        self.n_top = len(smiles_targets) if n_top is None else int(n_top)
+        self.agg = agg
+        self.calls = 0
+
+    def raw_score(self, smiles):
+        self.calls += 1
+        z = self.model.encode(self.collate_fn([smiles]))
+        norm = torch.norm(self.z_targets - z, dim=1).sort()[0][:self.n_top].detach().numpy()
+        return {"mean": norm.mean, "max": norm.max, "min": norm.min}[self.agg]()
+
+    def score(self, s):
+        return float(np.exp(-self.raw_score(s)))
+
+    def score_list(self, smiles):
+        return [self.score(s) for s in smiles]
+
+
+class _Aggregate:
+    def __init__(self, fns):
+        self.scoring_functions = fns
+
+    def score_list(self, smiles):
+        return list(np.mean([f.score_list(smiles) for f in self.scoring_functions], axis=0))
+
+
+def test_generate_scoring_glue_latent_distance(tmp_path):
+    """the reference's scoring builder loads the scorer's VAE with `.to("cpu")` (utils.py:292) and does host
+    arithmetic on encode()'s result.  HostScoringVAE serves that sequence from the MI355X; BatchedObjective answers the
+    same raw_score calls from ONE batched encoder pass, with and without host threads: identical scores."""
+    from polygon_amd.utils.utils import load_model, save_model
+    from polygon_amd.vae.scoring import BatchedObjective, HostScoringVAE
+    base, P = build_model(REAL, 13, "fp32")
+    ckpt = tmp_path / "scorer.pt"
+    save_model(base, str(ckpt))
+    HostScoringVAE.compute_device = "cuda:0"
+    m = load_model(HostScoringVAE, str(ckpt), "cpu")              # what utils.py:292 does with vae_model=HostScoringVAE
+    assert m.device.type == "cuda" and not m.training
+    targets = list(O.synthetic_smiles(9, seed=31))
+    mols = list(O.synthetic_smiles(150, seed=32)) + ["C", ""]
+    ld1 = _RefLikeLatentDistance(targets, m, n_top=3, agg="mean")
+    ld2 = _RefLikeLatentDistance(targets, m, n_top=None, agg="max")
+    assert ld1.z_targets.device.type == "cpu"
+    agg = _Aggregate([ld1, ld2])
+    ref = agg.score_list(mols[:40])                                # one molecule at a time, as the reference
+    assert ld1.calls == 40
+    # against the oracle's mu for one molecule
+    enc = O.encoder_forward(P, O.collate([mols[0]]), np.zeros((1, REAL["Dz"])), keep=False)
+    zt = O.encoder_forward(P, O.collate(targets), np.zeros((len(targets), REAL["Dz"])), keep=False)["mu"]
+    want = np.sort(np.linalg.norm(zt - enc["mu"], axis=1))[:3].mean()
+    assert abs(ld1.raw_score(mols[0]) - want) <= 1e-3 * want
+    for n_jobs in (1, 4):
+        ld1.calls = ld2.calls = 0
+        bo = BatchedObjective(_Aggregate([ld1, ld2]), n_jobs=n_jobs)
+        assert len(bo.latent) == 2
+        got = bo.score_list(mols)
+        assert ld1.calls == 0 and ld2.calls == 0                   # every raw score came from the batched pass
+        assert np.abs(np.array(got[:40]) - np.array(ref)).max() <= 1e-5
+        # a string outside the primed table falls back to the scorer's own code
+        assert abs(ld1.raw_score("CCCCO") - _RefLikeLatentDistance(targets, m, n_top=3).raw_score("CCCCO")) <= 1e-6
+        ld1.raw_score, ld2.raw_score = type(ld1).raw_score.__get__(ld1), type(ld2).raw_score.__get__(ld2)
+
+
+def test_sample_sharded_single_process_is_deterministic_in_seed():
+    model, _ = build_model(REAL, 4, "bf16", eos_bias=1.0)
+    model.eval()
+    a = model.sample_sharded(300, max_len=40, seed=11)
+    b = model.sample_sharded(300, max_len=40, seed=11)
+    c = model.sample_sharded(300, max_len=40, seed=12)
+    assert len(a) == 300 and a == b and a != c
+
+
+def test_generate_loop_at_configs4_sizes(tmp_path):
+    """configs[4] at its real sizes - mols_to_sample 8192, keep_top 4096, optimize_batch_size 512, 2 fine-tune epochs,
+    max_len 100 - with a stub host scorer (RDKit scoring stays on the host, out of scope) and an identity canonicaliser;
+    two generations; the phase timings the reference logs (vae_generator.py:190-193) are kept."""
+    from polygon_amd.vae.vae_generator import SmilesVaeMoleculeGenerator
+    model, _ = build_model(REAL, 9, "bf16", eos_bias=1.0, d_dropout=0.2)
+
+    class Obj:
+        def score_list(self, smiles):
+            return [min(len(s), 40) / 40.0 for s in smiles]
+    gen = SmilesVaeMoleculeGenerator(model, max_len=100, device=torch.device("cuda:0"), out_dir=str(tmp_path),
+                                     canonicalizer=lambda s, include_stereocenters=True: [x for x in s if x], n_jobs=2)
+    res = gen.optimise(Obj(), [], keep_top=4096, n_epochs=2, mols_to_sample=8192, optimize_n_epochs=2,
+                       optimize_batch_size=512, pretrain_n_epochs=1, save_frequency=1)
+    assert 4096 < len(res) <= 8192 and res == sorted(res, reverse=True)
+    assert len(gen.timings) == 2 and all(t > 0 for ph in gen.timings for t in ph)
+    print("configs[4] phases (s) sample / score / fine-tune:", [tuple(round(t, 3) for t in ph) for ph in gen.timings])
+    assert (tmp_path / "GDM_2.pt").exists() and (tmp_path / "GDM_ongoing_top_scoring_molecules.txt").exists()

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r'''
 import os, sys, faulthandler
-faulthandler.dump_traceback_later(60, exit=False)   # if a rank stalls, its stack goes to stderr before the parent gives up
+faulthandler.dump_traceback_later(110, exit=False)   # if a rank stalls, its stack goes to stderr before the parent gives up
 sys.path.insert(0, %r)
 import numpy as np, torch, torch.distributed as dist
 from polygon_amd.parallel import init_distributed, GradComm
@@ -75,6 +75,38 @@ if rank == 0:
         got = recon * n_b / 2.0                   # two batches carried a loss in either pass
         assert 3.6 < got < 4.3, (r, got)          # ~ log(51) = 3.93 for a near-untrained model; a rank's share would be ~1.97
 print("rank", rank, "trainer ok", flush=True)
+
+# sharded sampling: rows split over the ranks, one final gather; same strings as ONE process decoding every row
+model.eval()
+n, ml, seed = 101, 30, 5
+z_all = torch.randn(n, REAL["Dz"], device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(seed))
+tok, ep = model.sample_tokens(n, max_len=ml, z=z_all, seed=seed, row_offset=0)
+want = model.vocabulary.decode_batch(tok.cpu().numpy(), ep.cpu().numpy())
+got = model.sample_sharded(n, max_len=ml, seed=seed)
+assert got == want, "sharded sampling differs from the single-process strings"
+got2 = model.sample_sharded(n, max_len=ml)          # seed drawn on rank 0 and broadcast: the ranks still agree
+both = [None, None]; dist.all_gather_object(both, got2); assert both[0] == both[1]
+
+# generate loop under data parallelism: sharded sampling, scoring split over the ranks, one shuffle, DP fine-tune
+from polygon_amd.vae.vae_generator import SmilesVaeMoleculeGenerator
+class Obj:
+    def __init__(self): self.n = 0
+    def score_list(self, smiles):
+        self.n += len(smiles)
+        return [min(len(s), 30) / 30.0 for s in smiles]
+obj = Obj()
+out = os.path.join(%r, "gen%%d" %% rank); os.makedirs(out, exist_ok=True)
+gen = SmilesVaeMoleculeGenerator(model, max_len=40, device=torch.device("cuda:0"), out_dir=out,
+                                 canonicalizer=lambda s, include_stereocenters=True: [x for x in s if x])
+gen.trainer.n_batch = 32
+res = gen.optimise(obj, [], keep_top=128, n_epochs=2, mols_to_sample=256, optimize_n_epochs=2, optimize_batch_size=32,
+                   pretrain_n_epochs=1, save_frequency=1)
+mine = [(r.smiles, r.score) for r in res]
+both = [None, None]; dist.all_gather_object(both, (mine, obj.n))
+assert both[0][0] == both[1][0] and len(mine) > 0, "ranks disagree on the generation's results"
+assert abs(both[0][1] - both[1][1]) <= 2            # each rank scored about half of every payload
+assert os.path.exists(os.path.join(out, "GDM_2.pt")) == (rank == 0)
+print("rank", rank, "generate ok", flush=True)
 dist.barrier(); dist.destroy_process_group()
 '''
 
@@ -170,7 +202,7 @@ def test_nccl_world1_gradcomm_with_persistent_kernels(tmp_path):
 
 def test_two_rank_step_equals_single_process(tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % (ROOT, str(tmp_path)))
+    script.write_text(WORKER % (ROOT, str(tmp_path), str(tmp_path)))
     # Two plain interpreter processes with the rendezvous variables set by hand: torch.distributed.run pulls in the whole
     # elastic-agent stack, whose first import on a fresh box (cold page cache) has taken more than two minutes.
     # The ranks share ONE GPU here, so they use the per-step decoder kernels (bits 2 | 4): a group-persistent launch needs
@@ -186,7 +218,7 @@ def test_two_rank_step_equals_single_process(tmp_path):
     outs = []
     try:
         for p in procs:
-            outs.append(p.communicate(timeout=100))
+            outs.append(p.communicate(timeout=130))
     except subprocess.TimeoutExpired:
         for p in procs:
             p.kill()
@@ -197,3 +229,4 @@ def test_two_rank_step_equals_single_process(tmp_path):
         assert p.returncode == 0, so[-3000:] + se[-5000:]
     assert sum(so.count("ok grad_rel_err") for so, _ in outs) == 4
     assert sum(so.count("trainer ok") for so, _ in outs) == 2
+    assert sum(so.count("generate ok") for so, _ in outs) == 2
