@@ -340,6 +340,7 @@ def main():
     ap.add_argument("--no_roofline", action="store_true")
     ap.add_argument("--no_e2e", action="store_true")
     ap.add_argument("--no_other_scaling", action="store_true")
+    ap.add_argument("--no_proxy", action="store_true")
     args = ap.parse_args()
 
     rank, world, local = init_distributed()
@@ -383,7 +384,7 @@ def main():
         other = {"scaling": mode, "value": tokens2 / dt2, "unit": "tokens/s", "ms_per_step": dt2 / args.steps * 1e3,
                  "global_batch": ng2, "rows_per_gpu": ng2 // world}
     proxy = None
-    if world == 1:   # the step a rank would run under strong scaling of the 1024-row global batch (no all-reduce)
+    if world == 1 and not args.no_proxy:   # the step a rank would run under strong scaling of the 1024-row global batch (no all-reduce)
         proxy = {}
         for nb in (512, 256, 128):
             strings = synthetic_smiles(n_pool * nb, seed=20250310)
