@@ -183,13 +183,22 @@ int launch_gemm_tn(const T* A, long lda, const T* B, long ldb, int M, int N, int
   PG_REQUIRE(lda % EPC == 0 && ldb % EPC == 0, "gemm_tn: lda/ldb must be multiples of %d", EPC);
   PG_REQUIRE(lda >= (M + EPC - 1) / EPC * EPC && ldb >= (N + EPC - 1) / EPC * EPC, "gemm_tn: rows must be padded to whole chunks");
   PG_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm_tn: operands must be 16-byte aligned");
-  static const int tn_blocks = getenv("PG_TN_BLOCKS") ? atoi(getenv("PG_TN_BLOCKS")) : 384;   // tuning aids
-  static const int tn_bkr = getenv("PG_TN_BKR") ? atoi(getenv("PG_TN_BKR")) : 64;
-  if (tn_bkr == 64)
-    return launch_gemm_tn_cfg<TileTN<T, 128, 128, 64, 2, 2>>(A, lda, B, ldb, M, N, R, C, ldc, alpha, alpha_dev, tn_blocks, colsum_a,
-                                                             colsum_b, stream);
-  return launch_gemm_tn_cfg<TileTN<T, 128, 128, 32, 2, 2>>(A, lda, B, ldb, M, N, R, C, ldc, alpha, alpha_dev, tn_blocks, colsum_a,
-                                                           colsum_b, stream);
+  // Measured on the decoder's weight-gradient shape (1536 x 512 x 50 k rows, bf16): 64-row tiles, one tile in flight, 384
+  // blocks 133 us; 32-row tiles (40 KB of LDS: three blocks per CU), two tiles in flight, 768 blocks 108 us; deeper rings
+  // and 256-wide tiles are slower (registers / LDS cut the blocks per CU).  Few output tiles: fewer split-K blocks, whose
+  // fp32 atomics otherwise dominate (768 x 256: 48 us at 384 blocks, 59 us at 768).
+  static const int tn_blocks_env = getenv("PG_TN_BLOCKS") ? atoi(getenv("PG_TN_BLOCKS")) : 0;   // tuning aids
+  static const int tn_bkr = getenv("PG_TN_BKR") ? atoi(getenv("PG_TN_BKR")) : 32;
+  static const int tn_depth = getenv("PG_TN_DEPTH") ? atoi(getenv("PG_TN_DEPTH")) : 2;
+  const int tn_blocks = tn_blocks_env ? tn_blocks_env : (cdiv(M, 128) * cdiv(N, 128) >= 32 ? 768 : 384);
+#define PG_TN_CASE(BKR, DEP)                                                                                                    \
+  if (tn_bkr == BKR && tn_depth == DEP)                                                                                         \
+    return launch_gemm_tn_cfg<TileTN<T, 128, 128, BKR, 2, 2, DEP>>(A, lda, B, ldb, M, N, R, C, ldc, alpha, alpha_dev, tn_blocks, \
+                                                                  colsum_a, colsum_b, stream);
+  PG_TN_CASE(64, 1) PG_TN_CASE(32, 1) PG_TN_CASE(32, 2)
+#undef PG_TN_CASE
+  return launch_gemm_tn_cfg<TileTN<T, 128, 128, 32, 2, 2, 2>>(A, lda, B, ldb, M, N, R, C, ldc, alpha, alpha_dev, tn_blocks, colsum_a,
+                                                              colsum_b, stream);
 }
 
 template int launch_gemm_nt<float>(const float*, long, const float*, long, int, int, int, const GemmEpi<float>&, hipStream_t);

@@ -130,7 +130,7 @@ struct TrainWs {
   size_t d_sv[PG_MAX_LAYERS][5], d_gi, d_logits, d_dlogits;
   // backward
   size_t b_dGI_l[PG_MAX_LAYERS], b_dGH_l[PG_MAX_LAYERS], b_dhz_l[PG_MAX_LAYERS][2];
-  size_t b_dout, b_dGI, b_dGH, b_dhz[2], b_dh0, b_dh0_op, b_dzproj, b_dzproj_op, b_onehot, b_dT, b_dq, b_dq_op, b_dhfin;
+  size_t b_dout, b_dGI, b_dGH, b_dhz[2], b_dh0, b_dh0_op, b_dzproj, b_dzproj_op, b_onehot, b_dT, e_onehot, e_dT, b_dq, b_dq_op, b_dhfin;
   size_t total;
 };
 
@@ -171,7 +171,9 @@ static inline TrainWs train_ws_layout(const pg_dims* d, int dtype, long B, long 
   }
   w.b_dh0 = take(B * Hd * 4); w.b_dh0_op = take(B * Hd * es);
   w.b_dzproj = take(B * 3 * Hd * 4); w.b_dzproj_op = take(B * 3 * Hd * es);
-  w.b_onehot = take(Nm * Vp * es); w.b_dT = take(Vp * 3 * Hm * 4);
+  w.b_onehot = take(Nd * Vp * es); w.b_dT = take(Vp * 3 * Hd * 4);
+  // the encoder's own copies: its embedding-gradient tail runs beside the decoder's deferred one (pg_vae.hip)
+  w.e_onehot = take(Ne * Vp * es); w.e_dT = take(Vp * 3 * Hq * 4);
   w.b_dq = take(B * 2 * Dz * 4); w.b_dq_op = take(B * 2 * Dz * es); w.b_dhfin = take(B * Hq * 4);
   w.total = p;
   return w;

@@ -328,9 +328,10 @@ __device__ __forceinline__ void mma_mainloop_nt(f32x16 (&acc)[Cfg::TM][NACC], co
 
 // ---------------------------------------------------------------------------------------------------
 // TN engine: contraction over rows.
-template <typename T_, int BM_, int BN_, int BKR_, int WM_, int WN_> struct TileTN {
+template <typename T_, int BM_, int BN_, int BKR_, int WM_, int WN_, int DEPTH_ = 1> struct TileTN {
   using T = T_;
   static constexpr int BM = BM_, BN = BN_, BKR = BKR_, WM = WM_, WN = WN_;
+  static constexpr int DEPTH = DEPTH_;         // row tiles kept in flight in registers (global-load prefetch depth)
   static constexpr int NTHREADS = 64 * WM * WN;
   static constexpr int EPC = 16 / sizeof(T);
   static constexpr int PADB = sizeof(T) == 2 ? 64 : 16;
@@ -405,67 +406,91 @@ __device__ __forceinline__ void mma_mainloop_tn(f32x16 (&acc)[Cfg::TM][Cfg::TN],
   constexpr int NT = Cfg::NTHREADS, EPC = Cfg::EPC;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
-  uint4 ra[Cfg::A_IT], rb[Cfg::B_IT];
+  constexpr int D = Cfg::DEPTH;
+  uint4 ra[D][Cfg::A_IT], rb[D][Cfg::B_IT];   // register ring: tile j lives in slot j % D (static indices only)
   // descriptors start at this block's first row (r0) so that 32-bit byte offsets cover any split of a long operand
   const __amdgpu_buffer_rsrc_t arsrc = pg_make_rsrc(A + (long)r0 * lda);
   const __amdgpu_buffer_rsrc_t brsrc = pg_make_rsrc(B + (long)r0 * ldb);
   const int nk = (r1 - r0 + Cfg::BKR - 1) / Cfg::BKR;
-  auto gload = [&](int kt) __attribute__((always_inline)) {
+  auto gload = [&](int kt, auto slot_c) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slot_c)::value;
     const int rr = r0 + kt * Cfg::BKR;
 #pragma unroll
     for (int i = 0; i < Cfg::A_IT; ++i) {
       int id = tid + i * NT, kr = id / Cfg::ACH, c = id % Cfg::ACH;
       bool ok = id < Cfg::BKR * Cfg::ACH && rr + kr < r1 && m0 + c * EPC < Mtot;
-      ra[i] = pg_buf_load16(arsrc, ok ? (unsigned)(((long)(rr + kr - r0) * lda + m0 + c * EPC) * (long)sizeof(T)) : PG_OOB, 0);
+      ra[slot][i] = pg_buf_load16(arsrc, ok ? (unsigned)(((long)(rr + kr - r0) * lda + m0 + c * EPC) * (long)sizeof(T)) : PG_OOB, 0);
     }
 #pragma unroll
     for (int i = 0; i < Cfg::B_IT; ++i) {
       int id = tid + i * NT, kr = id / Cfg::BCH, c = id % Cfg::BCH;
       bool ok = id < Cfg::BKR * Cfg::BCH && rr + kr < r1 && n0 + c * EPC < Ntot;
-      rb[i] = pg_buf_load16(brsrc, ok ? (unsigned)(((long)(rr + kr - r0) * ldb + n0 + c * EPC) * (long)sizeof(T)) : PG_OOB, 0);
+      rb[slot][i] = pg_buf_load16(brsrc, ok ? (unsigned)(((long)(rr + kr - r0) * ldb + n0 + c * EPC) * (long)sizeof(T)) : PG_OOB, 0);
     }
   };
-  auto sstore = [&](int buf) __attribute__((always_inline)) {
+  auto sstore = [&](int buf, auto slot_c) __attribute__((always_inline)) {
+    constexpr int slot = decltype(slot_c)::value;
     char* sa = smem + buf * Cfg::STAGE_BYTES;
     char* sb = sa + Cfg::A_BYTES;
 #pragma unroll
     for (int i = 0; i < Cfg::A_IT; ++i) {
       int id = tid + i * NT, kr = id / Cfg::ACH, c = id % Cfg::ACH;
-      if (id < Cfg::BKR * Cfg::ACH) *reinterpret_cast<uint4*>(sa + kr * Cfg::ROWA + c * 16) = ra[i];
-      if (csa && id < Cfg::BKR * Cfg::ACH) chunk_accumulate<T>(ra[i], ca);
+      if (id < Cfg::BKR * Cfg::ACH) *reinterpret_cast<uint4*>(sa + kr * Cfg::ROWA + c * 16) = ra[slot][i];
+      if (csa && id < Cfg::BKR * Cfg::ACH) chunk_accumulate<T>(ra[slot][i], ca);
     }
 #pragma unroll
     for (int i = 0; i < Cfg::B_IT; ++i) {
       int id = tid + i * NT, kr = id / Cfg::BCH, c = id % Cfg::BCH;
-      if (id < Cfg::BKR * Cfg::BCH) *reinterpret_cast<uint4*>(sb + kr * Cfg::ROWBB + c * 16) = rb[i];
-      if (csb && id < Cfg::BKR * Cfg::BCH) chunk_accumulate<T>(rb[i], cb);
+      if (id < Cfg::BKR * Cfg::BCH) *reinterpret_cast<uint4*>(sb + kr * Cfg::ROWBB + c * 16) = rb[slot][i];
+      if (csb && id < Cfg::BKR * Cfg::BCH) chunk_accumulate<T>(rb[slot][i], cb);
     }
   };
   auto compute = [&](int buf) __attribute__((always_inline)) {
     const char* sa = smem + buf * Cfg::STAGE_BYTES;
     const char* sb = sa + Cfg::A_BYTES;
-#pragma unroll
-    for (int s = 0; s < Cfg::BKR / TnFrag<T>::KSTEP; ++s) {
-      uint4 fa[Cfg::TM], fb[Cfg::TN];
+    // fragments of k-step s+1 are requested BEFORE the MFMAs of step s (two register sets, pinned by scheduling
+    // barriers): left alone hipcc sinks every ds_read next to its MFMA and each k-step pays a full LDS latency - with
+    // one or two waves per SIMD nothing hides it (the kernel sat at 24 % matrix-pipe utilisation, LDS 24 % busy,
+    // L2 25 % busy: latency-bound inside the wave)
+    constexpr int S = Cfg::BKR / TnFrag<T>::KSTEP;
+    uint4 fa[2][Cfg::TM], fb[2][Cfg::TN];
+    auto lfrag = [&](int s, int set) __attribute__((always_inline)) {
 #pragma unroll
       for (int tm = 0; tm < Cfg::TM; ++tm)
-        fa[tm] = TnFrag<T>::load(sa, Cfg::ROWA, s * TnFrag<T>::KSTEP, wm * Cfg::WTM + tm * 32, lane);
+        fa[set][tm] = TnFrag<T>::load(sa, Cfg::ROWA, s * TnFrag<T>::KSTEP, wm * Cfg::WTM + tm * 32, lane);
 #pragma unroll
       for (int tn = 0; tn < Cfg::TN; ++tn)
-        fb[tn] = TnFrag<T>::load(sb, Cfg::ROWBB, s * TnFrag<T>::KSTEP, wn * Cfg::WTN + tn * 32, lane);
+        fb[set][tn] = TnFrag<T>::load(sb, Cfg::ROWBB, s * TnFrag<T>::KSTEP, wn * Cfg::WTN + tn * 32, lane);
+    };
+    lfrag(0, 0);
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      if (s + 1 < S) lfrag(s + 1, (s + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int tm = 0; tm < Cfg::TM; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < Cfg::TN; ++tn) TnFrag<T>::mma(acc[tm][tn], fa[tm], fb[tn]);
+        for (int tn = 0; tn < Cfg::TN; ++tn) TnFrag<T>::mma(acc[tm][tn], fa[s & 1][tm], fb[s & 1][tn]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
-  gload(0);
-  sstore(0);
+  // tiles 0..D-1 in flight, tile 0 staged; then per tile: refill the slot staged one iteration ago with tile kt+D (past
+  // the end it is fully predicated off: zeros, no traffic), contract tile kt, stage tile kt+1 (the oldest loads in flight).
+  // The tile count is rounded UP to a multiple of D and the unrolled body has no conditional: with a branch per tile hipcc
+  // loses the vmcnt bookkeeping across the back edge and drains the whole ring (vmcnt(0)) once per D tiles; the padding
+  // tiles contract zeros
+  static_for<D>([&](auto d) __attribute__((always_inline)) { gload(decltype(d)::value, d); });
+  sstore(0, IntC<0>{});
   __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    gload(kt + 1);   // the last one is fully predicated off (zeros into the idle buffer)
-    compute(kt & 1);
-    sstore((kt + 1) & 1);
-    __syncthreads();
+  const int nk_pad = (nk + D - 1) / D * D;
+  for (int kt0 = 0; kt0 < nk_pad; kt0 += D) {
+    static_for<D>([&](auto d) __attribute__((always_inline)) {
+      constexpr int dd = decltype(d)::value;
+      const int kt = kt0 + dd;
+      gload(kt + D, d);
+      compute(kt & 1);
+      sstore((kt + 1) & 1, IntC<(dd + 1) % D>{});
+      __syncthreads();
+    });
   }
 }

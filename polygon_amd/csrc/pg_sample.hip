@@ -109,6 +109,7 @@ extern "C" size_t pg_sample_workspace_bytes(const pg_dims* d, int dtype, int n) 
 }
 
 int check_persist();   // pg_vae.hip
+int shadow_join(hipStream_t st);
 static int sample_check_persist() { return check_persist(); }
 
 template <typename T>
@@ -220,6 +221,7 @@ extern "C" int pg_sample_forced(const pg_dims* d, int dtype, const float* params
   PG_REQUIRE(n >= 1, "pg_sample: n must be >= 1");
   PG_REQUIRE(!probs_out || multinomial, "pg_sample_forced: probabilities are only computed when multinomial != 0");
   PG_TRY(sample_check_persist());
+  PG_TRY(shadow_join((hipStream_t)stream));
   return dtype == PG_BF16 ? sample_t<bf16_t>(d, dtype, params, shadow, ws, ws_bytes, n, max_len, z, uniforms, seed, row_offset,
                                              temp, multinomial, tokens, end_pads, forced, probs_out, (hipStream_t)stream)
                           : sample_t<float>(d, dtype, params, shadow, ws, ws_bytes, n, max_len, z, uniforms, seed, row_offset,

@@ -93,59 +93,73 @@ extern "C" size_t pg_shadow_bytes(const pg_dims* d, int dtype) {
   return shadow_offsets(d, dtype).total;
 }
 
+// (deferred-work plumbing, defined further down)
+static int defer_fork(hipStream_t st, hipStream_t* side);
+static int shadow_fork_done(hipStream_t side, hipStream_t st);
+
 template <typename T>
-static int prepare_weights_t(const pg_dims* d, int dtype, const float* params, void* shadow, hipStream_t st) {
+static int prepare_weights_t(const pg_dims* d, int dtype, const float* params, void* shadow, hipStream_t st_main) {
   const ParamOff po = param_offsets(d);
   const ShadowOff so = shadow_offsets(d, dtype);
   const int Hq = d->Hq, Hd = d->Hd, Dz = d->Dz, E = d->E, V = d->V, Vp = vpad(d);
-  PG_CHECK_HIP(hipMemsetAsync(at<char>(shadow, so.fc_w), 0, so.tab_enc - so.fc_w, st));  // zero the padded fc rows
-  PG_CHECK_HIP(hipMemsetAsync(at<char>(shadow, so.fc_b), 0, (size_t)Vp * 4, st));
-  CopyTable tab;
-  tab.n = 0;
-  long maxel = 0;
-  auto add = [&](long src, size_t dst, int rows, int cols, int src_ld, int dst_ld, int tr, int f32) {
+  // While weight-gradient deferral is on (the fused trainer), the DECODER's shadows are rebuilt on the library's side
+  // stream, beside the encoder forward that follows (a 64-CU kernel that needs only the encoder's): pg_decoder_fwd /
+  // pg_decoder_bwd / pg_sample join it on entry.  Otherwise everything runs on the caller's stream.
+  hipStream_t sd = st_main;
+  PG_TRY(defer_fork(st_main, &sd));
+  PG_CHECK_HIP(hipMemsetAsync(at<char>(shadow, so.fc_w), 0, so.tab_enc - so.fc_w, sd));  // zero the padded fc rows
+  PG_CHECK_HIP(hipMemsetAsync(at<char>(shadow, so.fc_b), 0, (size_t)Vp * 4, sd));
+  CopyTable tabs[2];   // [0] encoder (caller's stream), [1] decoder
+  long maxel[2] = {0, 0};
+  tabs[0].n = tabs[1].n = 0;
+  auto add = [&](int which, long src, size_t dst, int rows, int cols, int src_ld, int dst_ld, int tr, int f32) {
     CopyDesc c = {src, dst, rows, cols, src_ld, dst_ld, tr, f32};
-    tab.d[tab.n++] = c;
-    if ((long)rows * cols > maxel) maxel = (long)rows * cols;
+    tabs[which].d[tabs[which].n++] = c;
+    if ((long)rows * cols > maxel[which]) maxel[which] = (long)rows * cols;
   };
-  add(po.enc_whh, so.enc_whh, 3 * Hq, Hq, Hq, Hq, 0, 0);
-  add(po.enc_whh, so.enc_whhT, 3 * Hq, Hq, Hq, 3 * Hq, 1, 0);
-  add(po.qmu_w, so.wq, Dz, Hq, Hq, Hq, 0, 0);
-  add(po.qlv_w, so.wq + (size_t)Dz * Hq * sizeof(T), Dz, Hq, Hq, Hq, 0, 0);
-  add(po.qmu_w, so.wqT, Dz, Hq, Hq, 2 * Dz, 1, 0);
-  add(po.qlv_w, so.wqT + (size_t)Dz * sizeof(T), Dz, Hq, Hq, 2 * Dz, 1, 0);
-  add(po.qmu_b, so.bq, 1, Dz, Dz, Dz, 0, 1);
-  add(po.qlv_b, so.bq + (size_t)Dz * 4, 1, Dz, Dz, Dz, 0, 1);
-  add(po.lat_w, so.lat_w, Hd, Dz, Dz, Dz, 0, 0);
-  add(po.lat_w, so.lat_wT, Hd, Dz, Dz, Hd, 1, 0);
-  add(po.dec_wih[0] + E, so.wih0z, 3 * Hd, Dz, E + Dz, Dz, 0, 0);
-  add(po.dec_wih[0] + E, so.wih0zT, 3 * Hd, Dz, E + Dz, 3 * Hd, 1, 0);
+  add(0, po.enc_whh, so.enc_whh, 3 * Hq, Hq, Hq, Hq, 0, 0);
+  add(0, po.enc_whh, so.enc_whhT, 3 * Hq, Hq, Hq, 3 * Hq, 1, 0);
+  add(0, po.qmu_w, so.wq, Dz, Hq, Hq, Hq, 0, 0);
+  add(0, po.qlv_w, so.wq + (size_t)Dz * Hq * sizeof(T), Dz, Hq, Hq, Hq, 0, 0);
+  add(0, po.qmu_w, so.wqT, Dz, Hq, Hq, 2 * Dz, 1, 0);
+  add(0, po.qlv_w, so.wqT + (size_t)Dz * sizeof(T), Dz, Hq, Hq, 2 * Dz, 1, 0);
+  add(0, po.qmu_b, so.bq, 1, Dz, Dz, Dz, 0, 1);
+  add(0, po.qlv_b, so.bq + (size_t)Dz * 4, 1, Dz, Dz, Dz, 0, 1);
+  add(1, po.lat_w, so.lat_w, Hd, Dz, Dz, Dz, 0, 0);
+  add(1, po.lat_w, so.lat_wT, Hd, Dz, Dz, Hd, 1, 0);
+  add(1, po.dec_wih[0] + E, so.wih0z, 3 * Hd, Dz, E + Dz, Dz, 0, 0);
+  add(1, po.dec_wih[0] + E, so.wih0zT, 3 * Hd, Dz, E + Dz, 3 * Hd, 1, 0);
   for (int l = 0; l < d->L; ++l) {
-    add(po.dec_whh[l], so.whh[l], 3 * Hd, Hd, Hd, Hd, 0, 0);
-    add(po.dec_whh[l], so.whhT[l], 3 * Hd, Hd, Hd, 3 * Hd, 1, 0);
+    add(1, po.dec_whh[l], so.whh[l], 3 * Hd, Hd, Hd, Hd, 0, 0);
+    add(1, po.dec_whh[l], so.whhT[l], 3 * Hd, Hd, Hd, 3 * Hd, 1, 0);
     if (l > 0) {
-      add(po.dec_wih[l], so.wih[l], 3 * Hd, Hd, Hd, Hd, 0, 0);
-      add(po.dec_wih[l], so.wihT[l], 3 * Hd, Hd, Hd, 3 * Hd, 1, 0);
+      add(1, po.dec_wih[l], so.wih[l], 3 * Hd, Hd, Hd, Hd, 0, 0);
+      add(1, po.dec_wih[l], so.wihT[l], 3 * Hd, Hd, Hd, 3 * Hd, 1, 0);
     }
   }
-  add(po.fc_w, so.fc_w, V, Hd, Hd, Hd, 0, 0);
-  add(po.fc_w, so.fc_wT, V, Hd, Hd, Vp, 1, 0);
-  add(po.fc_b, so.fc_b, 1, V, V, V, 0, 1);
-  PG_REQUIRE(tab.n <= PG_MAX_COPY, "copy table overflow");
-  hipLaunchKernelGGL(copy_table_kernel<T>, dim3(std::min<int>(cdiv(maxel, 256), 256), tab.n), dim3(256), 0, st, params,
-                     static_cast<char*>(shadow), tab);
+  add(1, po.fc_w, so.fc_w, V, Hd, Hd, Hd, 0, 0);
+  add(1, po.fc_w, so.fc_wT, V, Hd, Hd, Vp, 1, 0);
+  add(1, po.fc_b, so.fc_b, 1, V, V, V, 0, 1);
+  PG_REQUIRE(tabs[0].n <= PG_MAX_COPY && tabs[1].n <= PG_MAX_COPY, "copy table overflow");
+  // encoder part first, on the caller's stream: the encoder forward waits for nothing else
+  hipLaunchKernelGGL(copy_table_kernel<T>, dim3(std::min<int>(cdiv(maxel[0], 256), 256), tabs[0].n), dim3(256), 0, st_main, params,
+                     static_cast<char*>(shadow), tabs[0]);
   PG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gi_table_kernel, dim3(cdiv(3 * Hq, 256), V), dim3(256), 0, st, params + po.x_emb, E, params + po.enc_wih, E,
+  hipLaunchKernelGGL(gi_table_kernel, dim3(cdiv(3 * Hq, 256), V), dim3(256), 0, st_main, params + po.x_emb, E, params + po.enc_wih, E,
                      params + po.enc_bih, params + po.enc_bhh, Hq, at<float>(shadow, so.tab_enc));
   PG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gi_table_kernel, dim3(cdiv(3 * Hd, 256), V), dim3(256), 0, st, params + po.x_emb, E, params + po.dec_wih[0],
+  hipLaunchKernelGGL(copy_table_kernel<T>, dim3(std::min<int>(cdiv(maxel[1], 256), 256), tabs[1].n), dim3(256), 0, sd, params,
+                     static_cast<char*>(shadow), tabs[1]);
+  PG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gi_table_kernel, dim3(cdiv(3 * Hd, 256), V), dim3(256), 0, sd, params + po.x_emb, E, params + po.dec_wih[0],
                      E + Dz, params + po.dec_bih[0], params + po.dec_bhh[0], Hd, at<float>(shadow, so.tab_dec));
   PG_CHECK_LAUNCH();
   for (int l = 1; l < d->L; ++l) {
-    hipLaunchKernelGGL(bias_fold_kernel, dim3(cdiv(3 * Hd, 256)), dim3(256), 0, st, params + po.dec_bih[l], params + po.dec_bhh[l],
+    hipLaunchKernelGGL(bias_fold_kernel, dim3(cdiv(3 * Hd, 256)), dim3(256), 0, sd, params + po.dec_bih[l], params + po.dec_bhh[l],
                        Hd, at<float>(shadow, so.bias_gi[l]));
     PG_CHECK_LAUNCH();
   }
+  PG_TRY(shadow_fork_done(sd, st_main));
   return PG_OK;
 }
 
@@ -209,9 +223,11 @@ extern "C" int pg_check_failure(void* stream) {
 // pg_deferred_join.
 static int g_defer = 0;
 static int g_defer_dev = -1;
-static hipStream_t g_side = nullptr;
-static hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr;
+static hipStream_t g_side = nullptr, g_side2 = nullptr;   // large GEMMs / small latency-bound tail
+static hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr, g_ev_join2 = nullptr;
 static bool g_defer_pending = false;
+static hipEvent_t g_ev_shadow = nullptr;     // decoder shadows rebuilt on the side stream (pg_prepare_weights)
+static bool g_shadow_pending = false;
 extern "C" int pg_defer_weight_grads(int on) {
   const int old = g_defer;
   if (on >= 0) g_defer = on ? 1 : 0;
@@ -226,30 +242,52 @@ static int defer_fork(hipStream_t st, hipStream_t* side) {   // *side = stream f
     // default priority: a lowest-priority side stream was worth 15 us per step, but with two processes on one GPU (the
     // two-rank test) the low-priority queue was intermittently never scheduled and the step hung
     PG_CHECK_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+    PG_CHECK_HIP(hipStreamCreateWithFlags(&g_side2, hipStreamNonBlocking));
+    PG_CHECK_HIP(hipEventCreateWithFlags(&g_ev_join2, hipEventDisableTiming));
     PG_CHECK_HIP(hipEventCreateWithFlags(&g_ev_fork, hipEventDisableTiming));
     PG_CHECK_HIP(hipEventCreateWithFlags(&g_ev_join, hipEventDisableTiming));
+    PG_CHECK_HIP(hipEventCreateWithFlags(&g_ev_shadow, hipEventDisableTiming));
     g_defer_dev = dev;
   }
   if (dev != g_defer_dev) return PG_OK;   // one process per GPU is the model; another device simply does not defer
   PG_CHECK_HIP(hipEventRecord(g_ev_fork, st));
   PG_CHECK_HIP(hipStreamWaitEvent(g_side, g_ev_fork, 0));
+  PG_CHECK_HIP(hipStreamWaitEvent(g_side2, g_ev_fork, 0));
   *side = g_side;
   return PG_OK;
 }
+// the second side stream of the fork just made (the caller's stream itself when not deferring)
+static hipStream_t defer_second(hipStream_t side, hipStream_t st) { return side == st ? st : g_side2; }
 static int defer_done(hipStream_t side, hipStream_t st) {
   if (side == st) return PG_OK;
   PG_CHECK_HIP(hipEventRecord(g_ev_join, side));
+  PG_CHECK_HIP(hipEventRecord(g_ev_join2, g_side2));
   g_defer_pending = true;
   return PG_OK;
 }
 static int defer_join(hipStream_t st, bool clear) {
   if (g_defer_pending) {
     PG_CHECK_HIP(hipStreamWaitEvent(st, g_ev_join, 0));
+    PG_CHECK_HIP(hipStreamWaitEvent(st, g_ev_join2, 0));
     if (clear) g_defer_pending = false;
   }
   return PG_OK;
 }
 extern "C" int pg_deferred_join(void* stream) { return defer_join((hipStream_t)stream, false); }
+static int shadow_fork_done(hipStream_t side, hipStream_t st) {
+  if (side == st) return PG_OK;
+  PG_CHECK_HIP(hipEventRecord(g_ev_shadow, side));
+  g_shadow_pending = true;
+  return PG_OK;
+}
+// every consumer of the decoder's shadow weights calls this first
+int shadow_join(hipStream_t st) {
+  if (g_shadow_pending) {
+    PG_CHECK_HIP(hipStreamWaitEvent(st, g_ev_shadow, 0));
+    g_shadow_pending = false;
+  }
+  return PG_OK;
+}
 
 // the lane-order form of the saved gate activations packs (r, z) into d_sv[l][0..1] and (n, hn) into d_sv[l][2..3]: the
 // two arrays of a pair must be one contiguous region (they are, by construction of train_ws_layout; checked, not assumed)
@@ -583,6 +621,7 @@ extern "C" int pg_decoder_fwd(const pg_dims* d, int dtype, const float* params, 
   PG_TRY(check_dims(d, dtype));
   PG_TRY(check_persist());
   PG_REQUIRE(params && shadow && ws && d_tokens && z, "pg_decoder_fwd: NULL buffer");
+  PG_TRY(shadow_join((hipStream_t)stream));
   return dtype == PG_BF16
              ? decoder_fwd_t<bf16_t>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, d_tokens, h_lengths, z, dp, p_drop, seed,
                                      all_steps, save_for_backward, recon, logits_packed, (hipStream_t)stream)
@@ -691,11 +730,34 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
     PG_TRY(launch_gru_bwd_diag<T>(dg, st));
   }
   prof_end(1, pslot, st, sd.T + L, pflop);
-  // The five large weight-gradient GEMMs need nothing but the recurrence's outputs.  With deferral on they go to the side
-  // stream right here (forked behind the recurrence) and run beside the dz chain below - a string of small kernels that
-  // leaves the GPU idle - and beside pg_encoder_bwd; with deferral off they run here, in stream order.
-  hipStream_t sg = st;
-  PG_TRY(defer_fork(st, &sg));
+  // ---- the dz path: ALL the encoder BPTT waits for.  Stays on the caller's stream and is kept short: the row-segment sum
+  // of layer 0's dGI (the gradient of the per-sequence z projection), then dz = dzproj . W_ih0[:, E:] + dh0 . W_lat
+  T* dGI0 = at<T>(ws, w.b_dGI_l[0]);
+  float* dzp = at<float>(ws, w.b_dzproj);
+  T* dzp_op = at<T>(ws, w.b_dzproj_op);
+  hipLaunchKernelGGL(rowseg_sum_kernel<T>, dim3(cdiv(3 * Hd, 64 * (16 / (int)sizeof(T))), cdiv(B, 4)), dim3(256), 0, st, dGI0,
+                     at<int>(ws, w.dec_off), sd.T, 3 * Hd, B, dzp, dzp_op);
+  PG_CHECK_LAUNCH();
+  T* dh0_op = at<T>(ws, w.b_dh0_op);
+  if (!persist) PG_TRY(convert_to<T>(dh0, dh0_op, (long)B * Hd, st));
+  {
+    GemmEpi<T> e;
+    e.C32 = dz; e.ldc = Dz;
+    PG_TRY(launch_gemm_nt<T>(dzp_op, 3 * Hd, at<T>(shadow, so.wih0zT), 3 * Hd, B, Dz, 3 * Hd, e, st));
+  }
+  {
+    GemmEpi<T> e;
+    e.C32 = dz; e.ldc = Dz; e.accumulate = 1;
+    PG_TRY(launch_gemm_nt<T>(dh0_op, Hd, at<T>(shadow, so.lat_wT), Hd, B, Dz, Hd, e, st));
+  }
+  // The large weight-gradient GEMMs need nothing but the recurrence's outputs.  With deferral on they go to the side
+  // stream, forked BEHIND the dz chain above, and run beside pg_encoder_bwd (the encoder BPTT is a latency-bound kernel
+  // on a quarter of the CUs); with deferral off they run here, in stream order.  Forked right behind the recurrence
+  // they made the dz chain 3x slower (its small kernels are latency-bound, and memory latency under 768 resident GEMM
+  // blocks is several times the idle one): the encoder BPTT then started 420 us later than it could.
+  hipStream_t sg_big = st;
+  PG_TRY(defer_fork(st, &sg_big));
+  hipStream_t sg = sg_big;
   PG_TRY(launch_gemm_tn<T>(dlog, Vp, top, Hd, V, Hd, (int)Nd, grads + po.fc_w, Hd, 1.0f, s_ce, sg, grads + po.fc_b));   // decoder_fc
   for (int l = L - 1; l >= 0; --l) {
     T* dGI = at<T>(ws, w.b_dGI_l[l]);
@@ -709,41 +771,29 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
                                grads + po.dec_bih[l]));
     }
   }
-  PG_TRY(defer_done(sg, st));
-  // ---- the dz path (what the encoder BPTT waits for) and the small weight gradients
+  // ---- the small weight gradients feed nothing downstream: on a second side stream when deferring - a string of
+  // latency-bound kernels (130 us) that overlaps the large GEMMs instead of queueing behind them - else here in order
+  // (measured: they were 170 us of the 430-us chain between the recurrence and the encoder BPTT)
   {
-    T* dGI = at<T>(ws, w.b_dGI_l[0]);
+    hipStream_t sg = defer_second(sg_big, st);
     // layer 0 input = [x_emb[token] ; z]: token half through the gather table, z half per sequence
     T* oh = at<T>(ws, w.b_onehot);
     float* dT = at<float>(ws, w.b_dT);
-    hipLaunchKernelGGL(onehot_kernel<T>, dim3(ew_blocks(Nd * Vp)), dim3(256), 0, st, at<int>(ws, w.dec_tok), Nd, Vp, oh);
+    hipLaunchKernelGGL(onehot_kernel<T>, dim3(ew_blocks(Nd * Vp)), dim3(256), 0, sg, at<int>(ws, w.dec_tok), Nd, Vp, oh);
     PG_CHECK_LAUNCH();
-    PG_CHECK_HIP(hipMemsetAsync(dT, 0, (size_t)Vp * 3 * Hd * 4, st));
-    PG_TRY(launch_gemm_tn<T>(oh, Vp, dGI, 3 * Hd, Vp, 3 * Hd, (int)Nd, dT, 3 * Hd, 1.0f, nullptr, st, nullptr,
+    PG_CHECK_HIP(hipMemsetAsync(dT, 0, (size_t)Vp * 3 * Hd * 4, sg));
+    PG_TRY(launch_gemm_tn<T>(oh, Vp, dGI0, 3 * Hd, Vp, 3 * Hd, (int)Nd, dT, 3 * Hd, 1.0f, nullptr, sg, nullptr,
                              grads + po.dec_bih[0]));
     // d x_emb[v,e] += sum_g dT[v,g] W_ih0[g,e] ; d W_ih0[g,e] += sum_v dT[v,g] x_emb[v,e]
-    PG_TRY(small_gemm(dT, 3 * Hd, 1, params + po.dec_wih[0], E + Dz, 1, V, E, 3 * Hd, grads + po.x_emb, E, d->pad, st));
-    PG_TRY(small_gemm(dT, 1, 3 * Hd, params + po.x_emb, E, 1, 3 * Hd, E, V, grads + po.dec_wih[0], E + Dz, -1, st));
-    float* dzp = at<float>(ws, w.b_dzproj);
-    T* dzp_op = at<T>(ws, w.b_dzproj_op);
-    hipLaunchKernelGGL(rowseg_sum_kernel<T>, dim3(cdiv(3 * Hd, 256), B), dim3(256), 0, st, dGI, at<int>(ws, w.dec_off), sd.T,
-                       3 * Hd, dzp, dzp_op);
-    PG_CHECK_LAUNCH();
+    PG_TRY(small_gemm(dT, 3 * Hd, 1, params + po.dec_wih[0], E + Dz, 1, V, E, 3 * Hd, grads + po.x_emb, E, d->pad, sg));
+    PG_TRY(small_gemm(dT, 1, 3 * Hd, params + po.x_emb, E, 1, 3 * Hd, E, V, grads + po.dec_wih[0], E + Dz, -1, sg));
     PG_TRY(launch_gemm_tn<T>(dzp_op, 3 * Hd, at<T>(ws, w.d_zop), Dz, 3 * Hd, Dz, B, grads + po.dec_wih[0] + E, E + Dz, 1.0f,
-                             nullptr, st));
-    GemmEpi<T> e;
-    e.C32 = dz; e.ldc = Dz;
-    PG_TRY(launch_gemm_nt<T>(dzp_op, 3 * Hd, at<T>(shadow, so.wih0zT), 3 * Hd, B, Dz, 3 * Hd, e, st));
+                             nullptr, sg));
+    // decoder_lat: h0 = W z + b feeds every layer
+    PG_TRY(launch_gemm_tn<T>(dh0_op, Hd, at<T>(ws, w.d_zop), Dz, Hd, Dz, B, grads + po.lat_w, Dz, 1.0f, nullptr, sg,
+                             grads + po.lat_b));
   }
-  // decoder_lat: h0 = W z + b feeds every layer
-  T* dh0_op = at<T>(ws, w.b_dh0_op);
-  if (!persist) PG_TRY(convert_to<T>(dh0, dh0_op, (long)B * Hd, st));
-  PG_TRY(launch_gemm_tn<T>(dh0_op, Hd, at<T>(ws, w.d_zop), Dz, Hd, Dz, B, grads + po.lat_w, Dz, 1.0f, nullptr, st, grads + po.lat_b));
-  {
-    GemmEpi<T> e;
-    e.C32 = dz; e.ldc = Dz; e.accumulate = 1;
-    PG_TRY(launch_gemm_nt<T>(dh0_op, Hd, at<T>(shadow, so.lat_wT), Hd, B, Dz, Hd, e, st));
-  }
+  PG_TRY(defer_done(sg_big, st));
   return PG_OK;
 }
 
@@ -753,6 +803,7 @@ extern "C" int pg_decoder_bwd(const pg_dims* d, int dtype, const float* params, 
   PG_TRY(check_dims(d, dtype));
   PG_TRY(check_persist());
   PG_REQUIRE(params && shadow && ws && grads && dz, "pg_decoder_bwd: NULL buffer");
+  PG_TRY(shadow_join((hipStream_t)stream));
   return dtype == PG_BF16 ? decoder_bwd_t<bf16_t>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, h_lengths, dp, p_drop, seed,
                                                   all_steps, g_host, g_dev, grads, dz, (hipStream_t)stream)
                           : decoder_bwd_t<float>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, h_lengths, dp, p_drop, seed,
@@ -824,8 +875,10 @@ static int encoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   }
   PG_TRY(launch_gemm_tn<T>(dGH, 3 * Hq, at<T>(ws, w.e_sv[4]), Hq, 3 * Hq, Hq, (int)Ne, grads + po.enc_whh, Hq, 1.0f, nullptr, st,
                            grads + po.enc_bhh));
-  T* oh = at<T>(ws, w.b_onehot);
-  float* dT = at<float>(ws, w.b_dT);
+  // (own one-hot / table-gradient scratch and atomic accumulation into x_emb's gradient: the decoder's deferred tail may
+  // still be running on the side stream)
+  T* oh = at<T>(ws, w.e_onehot);
+  float* dT = at<float>(ws, w.e_dT);
   hipLaunchKernelGGL(onehot_kernel<T>, dim3(ew_blocks(Ne * Vp)), dim3(256), 0, st, at<int>(ws, w.enc_tok), Ne, Vp, oh);
   PG_CHECK_LAUNCH();
   PG_CHECK_HIP(hipMemsetAsync(dT, 0, (size_t)Vp * 3 * Hq * 4, st));

@@ -250,6 +250,16 @@ class _Engine:
         """forward + hand-written BPTT of  kl_weight * kl + recon  into the flat ``grads`` buffer (zeroed here).
         ``comm`` (optional polygon_amd.parallel.GradComm) all-reduces the decoder bucket while the encoder BPTT
         runs, then the encoder bucket.  Returns device scalars (kl, recon)."""
+        L = _lib.lib()
+        # deferral on for the whole step: the decoder's shadow weights are rebuilt on the library's side stream beside the
+        # encoder forward, its large weight-gradient GEMMs run there beside the dz chain and the encoder BPTT
+        old = L.pg_defer_weight_grads(1)
+        try:
+            return self._train_step(batch, kl_weight, grads, eps, dp, p_drop, seed, comm)
+        finally:
+            L.pg_defer_weight_grads(old)
+
+    def _train_step(self, batch, kl_weight, grads, eps, dp, p_drop, seed, comm):
         self.ensure_shadow()
         dev = self.flat.device
         B = len(batch)
@@ -274,14 +284,10 @@ class _Engine:
         # the decoder's large weight-gradient GEMMs run on the library's side stream, beside the dz chain and the encoder
         # BPTT (joined at the end of pg_encoder_bwd).  Under data parallelism the decoder bucket's all-reduce waits for
         # them on the communication stream (GradComm.start_decoder_bucket), not on this one.
-        old = L.pg_defer_weight_grads(1)
-        try:
-            self.decoder_bwd(ws, batch, dp, p_drop, seed, 0, 1.0, None, grads, dz)
-            if comm is not None:
-                comm.start_decoder_bucket(grads, self.decoder_param_start())
-            self.encoder_bwd(ws, batch, dp, dz, float(kl_weight), None, grads)
-        finally:
-            L.pg_defer_weight_grads(old)
+        self.decoder_bwd(ws, batch, dp, p_drop, seed, 0, 1.0, None, grads, dz)
+        if comm is not None:
+            comm.start_decoder_bucket(grads, self.decoder_param_start())
+        self.encoder_bwd(ws, batch, dp, dz, float(kl_weight), None, grads)
         if comm is not None:
             comm.finish(grads, self.decoder_param_start())
         return scal[0], scal[1]

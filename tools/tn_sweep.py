@@ -20,7 +20,10 @@ def bench(M, N, R, iters=50):
     print("M=%5d N=%5d R=%6d: %8.2f us  %7.1f TF/s" % (M, N, R, ms * 1e3, 2.0 * M * N * R / ms / 1e9), flush=True)
 
 print("PG_TN_BLOCKS=%s PG_TN_BKR=%s" % (os.environ.get("PG_TN_BLOCKS"), os.environ.get("PG_TN_BKR")))
-bench(1536, 512, 50000)
-bench(768, 256, 50000)
-bench(64, 1536, 50000)
-bench(1536, 128, 1024)
+if len(sys.argv) > 1 and sys.argv[1] == "one":
+    bench(1536, 512, 50000, iters=5)
+else:
+    bench(1536, 512, 50000)
+    bench(768, 256, 50000)
+    bench(64, 1536, 50000)
+    bench(1536, 128, 1024)
