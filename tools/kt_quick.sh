@@ -1,5 +1,5 @@
 # quick per-kernel times of the training step (development aid): rocprofv3 kernel trace over a short bench run
-set -e
+set +e
 export TMPDIR=/tmp
 R=$PWD; O=$R/gpurun_out
 python3 tools/step_timeline.py "$KT" > $O/step_timeline.txt 2>&1 || true
