@@ -299,30 +299,38 @@ def e2e_leg(args, dev, rank, world, barrier):
                     "fused step, epoch-end loss read-back; each rank tokenises only its shard"}
 
 
-def sample_leg(model, n, rank, world, dev, barrier, reps=3):
-    """n rows per GPU, max_len 100: token matrix + end positions INCLUDING the D2H copy (SURVEY.md 8d metric 2)."""
+def sample_leg(model, n, rank, world, dev, barrier, reps=3, all_steps=False):
+    """n rows per GPU, max_len 100: token matrix + end positions INCLUDING the D2H copy (SURVEY.md 8d metric 2).
+    Rows that have drawn their eos leave the decode (pg_persist_sample.hip, build_live_list); ``all_steps`` switches that
+    off (every row runs all 99 steps, as in round 1).  The flop rate counts the steps rows really ran."""
     z = torch.randn(n, model.d_z, device=dev)
-
-    def once(seed):
-        tok, ep = model.sample_tokens(n, max_len=100, z=z, seed=seed, row_offset=rank * n)
-        return tok.cpu(), ep.cpu()
-    once(1)
-    barrier()
-    t1 = time.perf_counter()
-    for r in range(reps):
-        once(2 + r)
-    barrier()
-    ds = max_over_ranks(time.perf_counter() - t1, world, dev)
-    # device-only time of the same call, for the split
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    model.sample_tokens(n, max_len=100, z=z, seed=9, row_offset=rank * n)
-    torch.cuda.synchronize()
-    dev_ms = (time.perf_counter() - t2) * 1e3
+    if all_steps:
+        os.environ["PG_SAMPLE_NO_COMPACT"] = "1"
+    try:
+        def once(seed):
+            tok, ep = model.sample_tokens(n, max_len=100, z=z, seed=seed, row_offset=rank * n)
+            return tok.cpu(), ep.cpu()
+        once(1)
+        barrier()
+        t1 = time.perf_counter()
+        for r in range(reps):
+            tok, ep = once(2 + r)
+        barrier()
+        ds = max_over_ranks(time.perf_counter() - t1, world, dev)
+        # device-only time of the same call, for the split
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        model.sample_tokens(n, max_len=100, z=z, seed=9, row_offset=rank * n)
+        torch.cuda.synchronize()
+        dev_ms = (time.perf_counter() - t2) * 1e3
+    finally:
+        os.environ.pop("PG_SAMPLE_NO_COMPACT", None)
     mol_s = reps * n * world / ds
+    # decode steps a row runs: up to and including the one that draws its eos (end position - 1), 99 without one
+    steps_run = 99.0 if all_steps else float((ep.double() - 1).clamp(max=99).mean())
     return {"value": mol_s, "unit": "molecules/s", "n_per_gpu": n, "max_len": 100, "ms_per_batch": ds / reps * 1e3,
-            "ms_per_batch_device_only": dev_ms, "includes_d2h": True,
-            "tflops": mol_s * SAMPLE_FLOP_PER_MOL / 1e12}
+            "ms_per_batch_device_only": dev_ms, "includes_d2h": True, "mean_decode_steps_per_row": steps_run,
+            "tflops": mol_s * SAMPLE_FLOP_PER_MOL * steps_run / 99.0 / 1e12}
 
 
 def main():
@@ -401,16 +409,24 @@ def main():
     if args.sample_n > 0:
         model.eval()
         sample = sample_leg(model, args.sample_n, rank, world, dev, barrier)
+        full = sample_leg(model, args.sample_n, rank, world, dev, barrier, all_steps=True)
         sample.update({"metric": "sampled_molecules_per_sec",
+                       "rows_leave_at_eos": "rows that have drawn eos are dropped from the decode (same tokens); the model is the "
+                                            "benchmark's random-init one after its few training steps, whose rows end by "
+                                            "chance (mean_decode_steps_per_row); all_steps = the same call with every row "
+                                            "decoded to max_len, the round-1 behaviour",
+                       "all_steps": {k: full[k] for k in ("value", "ms_per_batch", "ms_per_batch_device_only", "tflops")},
                        "kernel": "dec_sample_persist_kernel (the whole decode loop of up to 16384 rows in one group-persistent "
                                  "launch: 3 GRU layers + vocab projection + softmax + inverse-CDF draw)" if args.dtype == "bf16"
                                  else "gru_fwd2_kernel x3 + sample_head_kernel per step",
-                       "frac_of_mfma_peak": sample["value"] * SAMPLE_FLOP_PER_MOL / 1e12 / (PEAK[args.dtype] * world)})
+                       "frac_of_mfma_peak": sample["tflops"] / (PEAK[args.dtype] * world),
+                       "frac_of_mfma_peak_all_steps": full["tflops"] / (PEAK[args.dtype] * world)})
         if world == 1 and args.sample_extra:
             sample["more_rows"] = {}
             for n in [int(x) for x in args.sample_extra.split(",") if x]:
                 s = sample_leg(model, n, 0, 1, dev, barrier, reps=2 if n > 100000 else 3)
-                sample["more_rows"]["n_%d" % n] = {k: s[k] for k in ("value", "ms_per_batch", "ms_per_batch_device_only")}
+                sample["more_rows"]["n_%d" % n] = {k: s[k] for k in ("value", "ms_per_batch", "ms_per_batch_device_only",
+                                                                      "mean_decode_steps_per_row")}
 
     if rank == 0:
         out = {

@@ -163,6 +163,7 @@ struct DecSamplePersist {
   const uint8_t* forced = nullptr;
   float* probs_out = nullptr;
   long p_stride = 0;
+  int compact = 1;                            // ended rows leave the decode (tok = -1); 0: every row runs all T steps
   unsigned* sync = nullptr;                   // PG_SAMPLE_SYNC_WORDS words, zeroed by the launcher
   unsigned* fail = nullptr;                   // set by the launcher
   unsigned spin_limit = 0;                    // set by the launcher

@@ -39,9 +39,12 @@ constexpr int GATE_BYTES = 3 * CARRY_BYTES;
 constexpr int TILE_BYTES = ACT_BYTES + CARRY_BYTES;
 constexpr int TILE0_BYTES = ACT_BYTES / 2 + CARRY_BYTES + 2 * GATE_BYTES;
 constexpr int TOK_BYTES = 16 * PG_SAMPLE_MAX_TS * 4;
-constexpr int SMEM = WIN_BYTES + 2 * TILE_BYTES + 16;
-static_assert(2 * TILE0_BYTES + TOK_BYTES + 16 <= SMEM, "layer-0 layout must fit the common allocation");
-static_assert(2 * 16 * 1024 + 16 * 65 * 4 + 16 <= SMEM, "head layout must fit the common allocation");
+constexpr int LIST_BYTES = 16 * PG_SAMPLE_MAX_TS * 4 + 16;   // live-row list of the visit + the four waves' counts
+constexpr int SMEM = WIN_BYTES + 2 * TILE_BYTES + LIST_BYTES + 16;
+constexpr int LIST_OFF = SMEM - 16 - LIST_BYTES;
+static_assert(2 * TILE0_BYTES + TOK_BYTES <= LIST_OFF, "layer-0 layout must fit the common allocation");
+static_assert(2 * 16 * 1024 + 16 * 65 * 4 <= LIST_OFF, "head layout must fit the common allocation");
+static_assert(16 * PG_SAMPLE_MAX_TS <= 256, "one thread per row of a sub-batch builds the live list");
 static_assert(PG_SAMPLE_MAX_TS <= 2 * NH, "a head workgroup stages at most two tiles per visit");
 
 __device__ __forceinline__ f32x4 mma16(const bf16x8& w, const bf16x8& x, f32x4 c) {
@@ -79,6 +82,56 @@ __device__ __forceinline__ unsigned* counter(const DecSamplePersist& a, int g, i
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// Live rows of sub-batch [j0, j1) of group g at step t, compacted in row order: sList[k] = index within the sub-batch
+// of the k-th row that is still decoding, padded with -1 to a multiple of 16; sTokC[k] (layer 0) = the token that row
+// feeds.  tok[b] >= 0 is the token of a decoding row; a row whose eos was drawn at step te carries -1 - te and stays in
+// the lists up to and including step te + 1 (that last step is wasted: the head records nothing for it).  The extra
+// step buys this: the words that decide the list of visit (t, s) are those the head published up to step t - 2 -- all
+// complete once ANY stage has finished its (t-1, s) -- while everything published later (a token, -1 - (t-1), -1 - t)
+// reads as "live at t".  So every stage may load the words whenever it likes after its own (t-1, s), concurrently with
+// the head's writes, and all of them still build the same list: layers 1, 2 load them BEFORE they start to wait for
+// the stage below, which takes the L2 round trip off the ring's critical path; layer 0 and the head load them behind
+// their wait, because they need the newest value too (the token to feed; whether the row ended at t - 1).
+// Ended rows cost nothing from the second step on.  A row's arithmetic does not depend on its tile slot and its
+// uniforms are keyed by the row, so the tokens are those of the uncompacted decode.
+constexpr int NOT_A_ROW = -0x7fffffff - 1;
+__device__ __forceinline__ int load_tok_word(const DecSamplePersist& a, int g, int j0, int j1) {
+  const int tid = threadIdx.x;
+  const int b = g + NG * (16 * j0 + tid);
+  int tv = NOT_A_ROW;
+  if (tid < 16 * (j1 - j0) && b < a.n) tv = __hip_atomic_load(a.tok + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return tv;
+}
+// HEAD: entries carry 256 * (the row ended at t - 1) on top of the index.  Returns the live count.
+template <bool HEAD>
+__device__ __forceinline__ int build_live_list(int tv, int t, char* smem, int* sTokC) {
+  int* sList = reinterpret_cast<int*>(smem + LIST_OFF);
+  int* sCnt = sList + 16 * PG_SAMPLE_MAX_TS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool live = tv >= 0 || (tv != NOT_A_ROW && -1 - tv >= t - 1);
+  const unsigned long long m = __ballot(live);
+  const int pre = __popcll(m & ((1ull << lane) - 1ull));
+  if (lane == 0) sCnt[wave] = __popcll(m);
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int cw = sCnt[w];
+    off += w < wave ? cw : 0;
+    tot += cw;
+  }
+  if (live) {
+    sList[off + pre] = HEAD ? tid + (tv < 0 && -1 - tv < t ? 256 : 0) : tid;
+    if (sTokC) sTokC[off + pre] = tv >= 0 ? tv : 0;
+  }
+  if (tid >= tot && tid < ((tot + 15) & ~15)) {
+    sList[tid] = -1;
+    if (sTokC) sTokC[tid] = 0;
+  }
+  __syncthreads();
+  return tot;
+}
+
 // one GRU layer of the group: the tile loop of dec_fwd_body (pg_persist_dec.hip) without the training outputs
 template <bool L0>
 __device__ __forceinline__ void layer_body(const DecSamplePersist& a, int g, int l, int c, char* smem) {
@@ -89,7 +142,6 @@ __device__ __forceinline__ void layer_body(const DecSamplePersist& a, int g, int
   const int lr = lane & 15, lq = lane >> 4;
   const int uw = c * 64 + wave * 16;
   const int u0 = uw + lq * 4;
-  const int n = a.n;
 
   const bf16_t* Whh = a.Whh[l];
   const bf16_t* Wih = a.Wih[l];
@@ -131,6 +183,7 @@ __device__ __forceinline__ void layer_body(const DecSamplePersist& a, int g, int
   char* sT = L0 ? smem : sA;
   int* sTok = reinterpret_cast<int*>(smem + 2 * TILE0_BYTES);      // layer 0 only
   volatile unsigned* sFlagT = reinterpret_cast<volatile unsigned*>(smem + SMEM - 16);
+  const int* sList = reinterpret_cast<const int*>(smem + LIST_OFF);
   constexpr int NS = 2;                                            // stores per wave and tile: state, published h
   constexpr int ND = RP_WAVE + 1 + (L0 ? 6 : 0);                   // DMA instructions per wave and tile
   static_assert(ND == 9 || ND == 11, "unexpected tile shape");
@@ -141,9 +194,12 @@ __device__ __forceinline__ void layer_body(const DecSamplePersist& a, int g, int
     const bf16_t* hprev_base = a.hop[l][p];
     const bf16_t* x_base = L0 ? hprev_base : a.hop[l - 1][p ^ 1];
     const __amdgpu_buffer_rsrc_t r_h = pg_make_rsrc(a.hop[l][p ^ 1]);
+    int live_t = 0;
     for (int s = 0; s < a.S; ++s) {
       const int j0 = s * a.TS;
       const int j1 = j0 + a.TS < a.ntile ? j0 + a.TS : a.ntile;
+      int tv = 0;
+      if constexpr (!L0) tv = load_tok_word(a, g, j0, j1);   // in flight while thread 0 polls
       // ---- wait for (l, t-1, s) of every slice and for the stage below: (l-1, t, s), or the head's (t-1, s)
       if (tid == 0) {
         bool ok = wait_ge(counter(a, g, l, s), (unsigned)(NCU * t), err, a.fail, a.spin_limit);
@@ -157,35 +213,39 @@ __device__ __forceinline__ void layer_body(const DecSamplePersist& a, int g, int
       }
       __syncthreads();
       if (*sFlagT == 0u) return;   // block-uniform: somebody gave up
-      if constexpr (L0) {          // the sub-batch's tokens (drawn by the head workgroups in this launch: coherent loads)
-        for (int i = tid; i < 16 * (j1 - j0); i += 256) {
-          const int b = g + NG * (16 * j0 + i);
-          sTok[i] = b < n ? __hip_atomic_load(a.tok + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        }
-        __syncthreads();
-      }
+      // the sub-batch's live rows and (layer 0) their tokens, drawn by the head workgroups in this launch: coherent loads
+      if constexpr (L0) tv = load_tok_word(a, g, j0, j1);
+      const int nlive = build_live_list<false>(tv, t, smem, L0 ? sTok : nullptr);
+      const int nt = (nlive + 15) >> 4;   // tiles of this visit, block-uniform
+      live_t += nlive;
+      // global row of a list entry, -1: empty slot.  A tile's entries are read from LDS two tiles ahead (ent_*), at the
+      // top of the iteration that ends by staging it, so their latency is off the tile's critical path: er = the entry
+      // of row lane & 15 (the DMA rows of a wave come out of it by readlane), ec = the entry of the carry row
+      auto dec_row = [&](int li) __attribute__((always_inline)) { return li >= 0 ? g + NG * (16 * j0 + li) : -1; };
+      auto ent_r = [&](int jj) __attribute__((always_inline)) { return jj < nt ? sList[16 * jj + lr] : -1; };
+      auto ent_c = [&](int jj) __attribute__((always_inline)) { return jj < nt ? sList[16 * jj + wave * 4 + lq] : -1; };
+      auto ent_t = [&](int jj) __attribute__((always_inline)) { return L0 && jj < nt ? sTok[16 * jj + wave * 4 + lq] : 0; };
 
-      auto stage = [&](int j, int buf) __attribute__((always_inline)) {
+      auto stage = [&](int buf, int er, int ec, int tk) __attribute__((always_inline)) {
         char* tb = sT + buf * TILEB;
 #pragma unroll
         for (int i = 0; i < RP_WAVE; ++i) {
           const int rp = wave * RP_WAVE + i;
           const int row = rp / PARTS, part = rp % PARTS;
-          const int b = g + NG * (16 * j + row);
-          const int bs = b < n ? b : g;
+          const int b = dec_row(__builtin_amdgcn_readlane(er, row));
+          const int bs = b >= 0 ? b : g;
           const bf16_t* src = (part == 0 ? hprev_base : x_base) + (long)bs * H + ((lane ^ (row & 15)) * 8);
           char* dst = tb + row * (PARTS * 1024) + part * 1024;
           __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, AUX_SC1);
         }
         {
           const int row = wave * 4 + (lane >> 4), ch = (lane & 15) ^ row;
-          const int i = 16 * j + row;
-          const int b = g + NG * i;
-          const int bs = b < n ? b : g;
+          const int b = dec_row(ec);
+          const int bs = b >= 0 ? b : g;
           char* eb = tb + ACTB + wave * 1024;
           __builtin_amdgcn_global_load_lds((gptr_t)(carry_src + (long)bs * H + ch * 4), (lptr_t)eb, 16, 0, 0);
           if constexpr (L0) {
-            const float* tp = a.table + (long)sTok[i - 16 * j0] * 3 * H + c * 64 + ch * 4;
+            const float* tp = a.table + (long)tk * 3 * H + c * 64 + ch * 4;
             const float* zp = a.zproj + (long)bs * 3 * H + c * 64 + ch * 4;
 #pragma unroll
             for (int gt = 0; gt < 3; ++gt) {
@@ -195,9 +255,10 @@ __device__ __forceinline__ void layer_body(const DecSamplePersist& a, int g, int
           }
         }
       };
-      stage(j0, 0);
-      if (j1 - j0 > 1) {           // block-uniform
-        stage(j0 + 1, 1);
+      int er0 = ent_r(0), er1 = ent_r(1);
+      if (nt > 0) stage(0, er0, ent_c(0), ent_t(0));
+      if (nt > 1) {                // block-uniform
+        stage(1, er1, ent_c(1), ent_t(1));
         if constexpr (ND == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
       } else {
@@ -205,10 +266,11 @@ __device__ __forceinline__ void layer_body(const DecSamplePersist& a, int g, int
       }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      for (int j = j0; j < j1; ++j) {
-        const int buf = (j - j0) & 1;
-        const int b = g + NG * (16 * j + lr);
-        const bool live = b < n;
+      for (int j = 0; j < nt; ++j) {
+        const int buf = j & 1;
+        const int er2 = ent_r(j + 2), ec2 = ent_c(j + 2), tk2 = ent_t(j + 2);
+        const int b = dec_row(er0);
+        const bool live = b >= 0;
         const char* tb = sT + buf * TILEB;
         f32x4 acc[4];
 #pragma unroll
@@ -292,12 +354,12 @@ __device__ __forceinline__ void layer_body(const DecSamplePersist& a, int g, int
           h[e] = (1.0f - z) * nn + z * hp4[e];
         }
         // tile j+1 has landed: everything older than the previous tile's NS stores (see pg_persist_dec.hip)
-        if (j > j0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if (j > 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         static_assert(NS == 2, "the wait above counts two stores per tile");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (j + 2 < j1) stage(j + 2, buf);           // block-uniform
+        if (j + 2 < nt) stage(buf, er2, ec2, tk2);   // block-uniform
         asm volatile("" ::: "memory");
         {
           const unsigned oob = 0x80000000u;          // beyond the descriptor's records: the store is dropped
@@ -306,12 +368,14 @@ __device__ __forceinline__ void layer_body(const DecSamplePersist& a, int g, int
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, to_bf16x4(h)), r_h,
                                                 (int)(live ? (unsigned)(((long)b * H + u0) * 2) : oob), 0, AUX_SC1);
         }
+        er0 = er1; er1 = er2;
       }
       // ---- publish (t, s) of this unit slice
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(counter(a, g, l, s), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (live_t == 0) return;       // every row of the group has ended: all its stages see that at this same step
   }
 }
 
@@ -320,10 +384,11 @@ __device__ __forceinline__ void head_body(const DecSamplePersist& a, int g, int 
   char* sA = smem;                                                 // 2 x [16 rows][1 KB], chunk q of row r at q ^ r
   float* sl = reinterpret_cast<float*>(smem + 2 * 16 * 1024);      // [16][65] logits, then exp, then probabilities
   volatile unsigned* sFlagT = reinterpret_cast<volatile unsigned*>(smem + SMEM - 16);
+  const int* sList = reinterpret_cast<const int*>(smem + LIST_OFF);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
-  const int n = a.n, V = a.V, top = a.L - 1;
+  const int V = a.V, top = a.L - 1;
   bf16x8 wf[KS];                                                   // W_fc rows 16*wave + lr (padded to 64 rows)
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
@@ -340,6 +405,7 @@ __device__ __forceinline__ void head_body(const DecSamplePersist& a, int g, int 
   for (int t = 0; t < a.T; ++t) {
     const int step = t + 1;                                        // column of the token matrix this step fills
     const bf16_t* htop = a.hop[top][(t & 1) ^ 1];
+    int live_t = 0;
     for (int s = 0; s < a.S; ++s) {
       const int j0 = s * a.TS;
       const int j1 = j0 + a.TS < a.ntile ? j0 + a.TS : a.ntile;
@@ -351,19 +417,26 @@ __device__ __forceinline__ void head_body(const DecSamplePersist& a, int g, int 
       }
       __syncthreads();
       if (*sFlagT == 0u) return;
+      const int nlive = build_live_list<true>(load_tok_word(a, g, j0, j1), t, smem, nullptr);
+      const int nt = (nlive + 15) >> 4;
+      live_t += nlive;
+      auto row_b = [&](int jj, int row) __attribute__((always_inline)) {
+        const int li = sList[16 * jj + row];
+        return li >= 0 ? g + NG * (16 * j0 + (li & 255)) : -1;
+      };
       // both tiles of the visit are requested at once
-      for (int j = j0 + hc, q = 0; j < j1; j += NH, ++q) {
+      for (int j = hc, q = 0; j < nt; j += NH, ++q) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = wave * 4 + i;
-          const int b = g + NG * (16 * j + row);
-          const int bs = b < n ? b : g;
+          const int b = row_b(j, row);
+          const int bs = b >= 0 ? b : g;
           __builtin_amdgcn_global_load_lds((gptr_t)(htop + (long)bs * H + ((lane ^ row) * 8)),
                                            (lptr_t)(sA + q * 16 * 1024 + row * 1024), 16, 0, AUX_SC1);
         }
       }
-      for (int j = j0 + hc, q = 0; j < j1; j += NH, ++q) {
-        if (q == 0 && j + NH < j1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // block-uniform
+      for (int j = hc, q = 0; j < nt; j += NH, ++q) {
+        if (q == 0 && j + NH < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // block-uniform
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -407,16 +480,16 @@ __device__ __forceinline__ void head_body(const DecSamplePersist& a, int g, int 
 #pragma unroll
           for (int e = 0; e < 4; ++e) y[sq * 4 + e] = ex[e] / sum;
           if (a.probs_out) {                                       // parity hook: the probabilities the draw below sees
-            const int b = g + NG * (16 * j + srow);
-            if (b < n)
+            const int b = row_b(j, srow);
+            if (b >= 0)
               *reinterpret_cast<f32x4*>(a.probs_out + ((long)(step - 1) * a.p_stride + b) * 64 + sq * 4) =
                   f32x4{ex[0] / sum, ex[1] / sum, ex[2] / sum, ex[3] / sum};
           }
           __syncthreads();
           if (sq == 0) {
-            const int b = g + NG * (16 * j + srow);
+            const int b = row_b(j, srow);
             float u = 2.0f;
-            if (b < n) {
+            if (b >= 0) {
               if (a.uniforms) u = a.uniforms[(long)(step - 1) * a.u_stride + b];
               else {
                 const unsigned long long gr = (unsigned long long)(a.row_offset + b);
@@ -435,14 +508,23 @@ __device__ __forceinline__ void head_body(const DecSamplePersist& a, int g, int 
           }
         }
         if (sq == 0) {
-          const int b = g + NG * (16 * j + srow);
-          if (b < n) {
-            const int fed = a.forced ? (int)a.forced[(long)b * a.max_len + step] : w;      // parity hook: teacher forcing
-            __hip_atomic_store(a.tok + b, fed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // published for layer 0
-            if (!a.eos[b]) {                                       // eos[b] is only ever touched by this workgroup
+          const int li = sList[16 * j + srow];
+          if (li >= 0 && li < 256) {                               // a row, and not one that ended a step ago
+            const int b = g + NG * (16 * j0 + li);
+            int fed = a.forced ? (int)a.forced[(long)b * a.max_len + step] : w;      // parity hook: teacher forcing
+            // eos[b]: written and read by one workgroup when compact == 0 (the list never changes); otherwise a row in
+            // the list with li < 256 has not ended, whichever workgroup serves it now
+            if (!a.eos[b]) {
               a.tokens[(long)b * a.max_len + step] = (uint8_t)w;
-              if (w == a.eos_id) { a.end_pads[b] = step + 1; a.eos[b] = 1; }
+              if (w == a.eos_id) {
+                a.end_pads[b] = step + 1;
+                a.eos[b] = 1;
+                // an ended row leaves the decode (nothing it would still compute is ever recorded); the teacher-forced
+                // hook keeps every row to the last step: its probability dump is compared along the forced stream
+                if (a.compact) fed = -1 - t;
+              }
             }
+            __hip_atomic_store(a.tok + b, fed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // published for layer 0
           }
         }
         __syncthreads();                                           // sl is reused by the next tile
@@ -451,6 +533,7 @@ __device__ __forceinline__ void head_body(const DecSamplePersist& a, int g, int 
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(counter(a, g, NSTAGE - 1, s), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (live_t == 0) return;       // the layers leave at this same step (build_live_list)
   }
 }
 

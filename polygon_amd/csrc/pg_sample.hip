@@ -169,6 +169,8 @@ static int sample_t(const pg_dims* d, int dtype, const float* params, const void
         pa.uniforms = uniforms ? uniforms + r0 : nullptr; pa.u_stride = n;
         pa.tokens = tokens + r0 * max_len; pa.end_pads = end_pads + r0;
         pa.forced = forced ? forced + r0 * max_len : nullptr;
+        const bool no_compact = getenv("PG_SAMPLE_NO_COMPACT") != nullptr;   // A/B aid, read per call
+        pa.compact = (forced || no_compact) ? 0 : 1;
         pa.probs_out = probs_out ? probs_out + r0 * 64 : nullptr; pa.p_stride = n;
         pa.sync = at<unsigned>(ws, w.sync);
         PG_TRY(launch_dec_sample_persist(pa, st));

@@ -100,6 +100,31 @@ def test_persistent_sampler_matches_per_step(n, max_len):
     assert sum(a == b for a, b in zip(ref, got)) >= 0.995 * n
 
 
+@pytest.mark.parametrize("n,eos_bias", [(37, 6.0), (1000, 3.0), (8192, 6.0), (16384, 4.0), (20000, 8.0)])
+def test_persistent_sampler_early_exit(n, eos_bias, monkeypatch):
+    """Ended rows leave the one-launch sampler (build_live_list: the live rows of a sub-batch are re-packed into tiles
+    at every visit, a group whose rows have all ended returns).  With an eos-biased head most rows end within a few
+    steps, so tiles shrink, sub-batches run empty and whole groups exit long before max_len: the tokens must be those of
+    the per-step kernels and of the same launch with compaction switched off (PG_SAMPLE_NO_COMPACT)."""
+    max_len = 100
+    model, _ = build_model(REAL, 32, "bf16", eos_bias=eos_bias)
+    model.eval()
+    z = torch.randn(n, REAL["Dz"], generator=torch.Generator().manual_seed(n)).cuda()
+    kw = dict(seed=991, row_offset=7, max_len=max_len, z=z)
+    ref = _sample(model, 8, n, **kw)
+    got = _sample(model, 0, n, **kw)
+    monkeypatch.setenv("PG_SAMPLE_NO_COMPACT", "1")
+    full = _sample(model, 0, n, **kw)
+    monkeypatch.delenv("PG_SAMPLE_NO_COMPACT")
+    assert (got[1] < max_len).mean() > 0.9 and np.median(got[1]) < 40, "the test needs rows that end early"
+    assert (full[0] == got[0]).all() and (full[1] == got[1]).all()   # same kernel, same arithmetic per row: bit-identical
+    same = (ref[0] == got[0]).all(1) & (ref[1] == got[1])
+    assert same.mean() >= 0.995, same.mean()
+    t, e = got[0].astype(np.int64), got[1].astype(np.int64)
+    cols = np.arange(max_len)[None, :]
+    assert (t[cols >= e[:, None]] == model.pad).all()
+
+
 def model_sample_argmax(model, mask, n, max_len, z):
     L = _lib.lib()
     old = L.pg_persist_disable(mask)
