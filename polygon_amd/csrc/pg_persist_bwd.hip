@@ -160,7 +160,11 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
       bool ok = wait_ge(cnt_own, (unsigned)(NCU * s), err, a.fail, a.spin_limit);
       if (has_up && ok) ok = wait_ge(cnt_up, (unsigned)(NCU * (s + 1)), err, a.fail, a.spin_limit);
       PG_STAMP(1);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      // No agent acquire (buffer_inv sc1, 0.7-1.2 us per step) here: everything another workgroup publishes is read with
+      // sc1 loads (LDS-DMA included), which are served by L2 and never by this CU's vector cache; the other loads of the
+      // step read what this workgroup wrote itself or what an earlier launch wrote.  The poll's value has returned
+      // (vmcnt(0) below), the barrier orders the other waves' loads behind it, and loads return in issue order.
+      if constexpr (AUXL == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // plain payload loads need it
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       *sFlag = ok ? 1u : 0u;
     }

@@ -207,7 +207,8 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
       bool ok = wait_ge(cnt_own, (unsigned)(NCU * t), err, a.fail, a.spin_limit);
       if (!L0 && ok) ok = wait_ge(cnt_low, (unsigned)(NCU * (t + 1)), err, a.fail, a.spin_limit);
       PG_STAMP(1);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      // no agent acquire: published rows are only ever read with sc1 loads (pg_persist_bwd.hip, same place)
+      if constexpr (AUXL == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       *sFlagT = ok ? 1u : 0u;
     }

@@ -207,7 +207,7 @@ __device__ __forceinline__ void layer_body(const DecSamplePersist& a, int g, int
           if constexpr (L0) ok = wait_ge(counter(a, g, NSTAGE - 1, s), (unsigned)(NH * t), err, a.fail, a.spin_limit);
           else ok = wait_ge(counter(a, g, l - 1, s), (unsigned)(NCU * (t + 1)), err, a.fail, a.spin_limit);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // no agent acquire: published rows and tokens are only read with sc1 / agent-scope loads (pg_persist_bwd.hip)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         *sFlagT = ok ? 1u : 0u;
       }
@@ -411,7 +411,7 @@ __device__ __forceinline__ void head_body(const DecSamplePersist& a, int g, int 
       const int j1 = j0 + a.TS < a.ntile ? j0 + a.TS : a.ntile;
       if (tid == 0) {
         const bool ok = wait_ge(counter(a, g, top, s), (unsigned)(NCU * (t + 1)), err, a.fail, a.spin_limit);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // no agent acquire: published rows and tokens are only read with sc1 / agent-scope loads (pg_persist_bwd.hip)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         *sFlagT = ok ? 1u : 0u;
       }
