@@ -32,3 +32,9 @@ int launch_gemm_nt(const T* A, long lda, const T* B, long ldb, int M, int N, int
 template <typename T>
 int launch_gemm_tn(const T* A, long lda, const T* B, long ldb, int M, int N, int R, float* C, long ldc, float alpha,
                    const float* alpha_dev, hipStream_t stream, float* colsum_a = nullptr, float* colsum_b = nullptr);
+
+// C[M,N] (fp32, ldc) += alpha * A[M,K] . B[N,K]^T, K split over blocks (atomic accumulation into an initialised C): for
+// outputs of a few tiles with a long K, where one block per tile is a latency chain.
+template <typename T>
+int launch_gemm_nt_splitk(const T* A, long lda, const T* B, long ldb, int M, int N, int K, float* C, long ldc, float alpha,
+                          hipStream_t stream);

@@ -57,6 +57,50 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_nt_kernel(const typename C
     }
 }
 
+// Split-K form for skinny outputs (few tiles, long K: the dz GEMMs behind the decoder BPTT, 8 tiles x K = 1536): one block
+// per (tile, K split), fp32 atomics into an initialised C.  8 blocks walking 24 K tiles each are a 38-us latency chain
+// on the step's critical path; 64 blocks of 3 tiles take a fifth of that.
+template <class Cfg>
+__global__ __launch_bounds__(Cfg::NTHREADS) void gemm_nt_splitk_kernel(const typename Cfg::T* __restrict__ A, long lda,
+                                                                        const typename Cfg::T* __restrict__ B, long ldb, int M,
+                                                                        int N, int K, int kt_per_split, float* __restrict__ C,
+                                                                        long ldc, float alpha) {
+  using T = typename Cfg::T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles_n = (N + Cfg::BN - 1) / Cfg::BN, tiles = ((M + Cfg::BM - 1) / Cfg::BM) * tiles_n;
+  const int tile = blockIdx.x % tiles, split = blockIdx.x / tiles;
+  const int bm = tile / tiles_n, bn = tile % tiles_n;
+  const int m0 = bm * Cfg::BM, n0 = bn * Cfg::BN;
+  const int nkt = (K + Cfg::BK - 1) / Cfg::BK;
+  const int kt0 = split * kt_per_split;
+  const int nk = min(kt_per_split, nkt - kt0);
+  if (nk <= 0) return;
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  {
+    const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+      for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = zacc;
+  }
+  RowSrc<T> as{A, lda, m0, M};
+  RowSrc<T> bs{B, ldb, n0, N};
+  mma_mainloop_nt<Cfg, Cfg::TN, Cfg::NGATE - 1>(acc, as, bs, K, smem, (int)threadIdx.x, kt0, nk);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+#pragma unroll
+  for (int tm = 0; tm < Cfg::TM; ++tm)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int m = m0 + Cfg::row_of(wm, tm, reg, lane);
+#pragma unroll
+      for (int tn = 0; tn < Cfg::TN; ++tn) {
+        const int n = n0 + Cfg::col_in_group(wn, tn, lane & 31);
+        if (m < M && n < N) atomicAdd(C + (long)m * ldc + n, acc[tm][tn][reg] * alpha);
+      }
+    }
+}
+
 template <class Cfg>
 __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_tn_kernel(const typename Cfg::T* __restrict__ A, long lda,
                                                                  const typename Cfg::T* __restrict__ B, long ldb, int M,
@@ -158,6 +202,26 @@ int launch_gemm_nt(const T* A, long lda, const T* B, long ldb, int M, int N, int
   return PG_OK;
 }
 
+template <typename T>
+int launch_gemm_nt_splitk(const T* A, long lda, const T* B, long ldb, int M, int N, int K, float* C, long ldc, float alpha,
+                          hipStream_t stream) {
+  constexpr int EPC = 16 / sizeof(T);
+  if (M <= 0 || N <= 0 || K <= 0) return PG_OK;
+  PG_REQUIRE(K % EPC == 0 && lda % EPC == 0 && ldb % EPC == 0, "gemm_nt_splitk: K/lda/ldb (%d,%ld,%ld) must be multiples of %d",
+             K, lda, ldb, EPC);
+  PG_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && C, "gemm_nt_splitk: operands must be 16-byte aligned");
+  using Cfg = TileCfg<T, 128, 128, 8, 2, 2>;
+  const int tiles = cdiv(M, Cfg::BM) * cdiv(N, Cfg::BN), nkt = cdiv(K, Cfg::BK);
+  // about one block per CU, at least 2 K tiles per block
+  int splits = max(1, min(nkt / 2, 256 / max(1, tiles)));
+  const int kt_per_split = cdiv(nkt, splits);
+  splits = cdiv(nkt, kt_per_split);
+  PG_LAUNCH_BIG_SMEM(gemm_nt_splitk_kernel<Cfg>, dim3(tiles * splits), dim3(Cfg::NTHREADS), Cfg::SMEM_BYTES, stream, A, lda, B, ldb,
+                     M, N, K, kt_per_split, C, ldc, alpha);
+  PG_CHECK_LAUNCH();
+  return PG_OK;
+}
+
 template <class Cfg, typename T>
 static int launch_gemm_tn_cfg(const T* A, long lda, const T* B, long ldb, int M, int N, int R, float* C, long ldc, float alpha,
                               const float* alpha_dev, int target_blocks, float* colsum_a, float* colsum_b, hipStream_t stream) {
@@ -205,3 +269,5 @@ template int launch_gemm_nt<float>(const float*, long, const float*, long, int, 
 template int launch_gemm_nt<bf16_t>(const bf16_t*, long, const bf16_t*, long, int, int, int, const GemmEpi<bf16_t>&, hipStream_t);
 template int launch_gemm_tn<float>(const float*, long, const float*, long, int, int, int, float*, long, float, const float*, hipStream_t, float*, float*);
 template int launch_gemm_tn<bf16_t>(const bf16_t*, long, const bf16_t*, long, int, int, int, float*, long, float, const float*, hipStream_t, float*, float*);
+template int launch_gemm_nt_splitk<float>(const float*, long, const float*, long, int, int, int, float*, long, float, hipStream_t);
+template int launch_gemm_nt_splitk<bf16_t>(const bf16_t*, long, const bf16_t*, long, int, int, int, float*, long, float, hipStream_t);

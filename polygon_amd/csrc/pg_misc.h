@@ -64,9 +64,12 @@ static __global__ void bias_fold_kernel(const float* __restrict__ bih, const flo
 
 // ---- packed batch ----------------------------------------------------------------------------------
 // mode 0: encoder (tok only).  mode 1: decoder (tok, target = next token, t, b) + offsets copy.
+// onehot (optional, [N, Vp], operand precision): row r = unit vector of tok[r] - the left operand of the embedding-table
+// gradient GEMM (one-hot^T . dGI), built here, in the forward pass, so that nothing of it is left for the step's tail
+template <typename T>
 static __global__ void build_packed_kernel(const int32_t* __restrict__ tokens, int B, int Tmax, int pad, Sched s, int mode,
                                     int* __restrict__ tok, int* __restrict__ tgt, int* __restrict__ rt, int* __restrict__ rb,
-                                    int* __restrict__ off_out) {
+                                    int* __restrict__ off_out, T* __restrict__ onehot, int Vp) {
   const int t = blockIdx.x;
   if (off_out && blockIdx.x == 0 && blockIdx.y == 0)
     for (int i = threadIdx.x; i <= s.T + 1; i += blockDim.x) off_out[i] = s.off[i];
@@ -74,24 +77,27 @@ static __global__ void build_packed_kernel(const int32_t* __restrict__ tokens, i
   const int b = blockIdx.y * blockDim.x + threadIdx.x;
   if (b >= Bt) return;
   const int r = s.off[t] + b;
-  tok[r] = tokens[(long)b * Tmax + t];
+  const int v = tokens[(long)b * Tmax + t];
+  tok[r] = v;
   if (mode == 1) {
     tgt[r] = (t + 1 < Tmax) ? tokens[(long)b * Tmax + t + 1] : pad;
     rt[r] = t;
     rb[r] = b;
   }
+  if (onehot) {   // Vp is a multiple of 16 / sizeof(T) (vpad): whole 16-byte chunks
+    constexpr int EPC = 16 / (int)sizeof(T);
+    uint4* row = reinterpret_cast<uint4*>(onehot + (long)r * Vp);
+    for (int c = 0; c < Vp / EPC; ++c) {
+      T e[EPC];
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) e[i] = from_f32<T>(c * EPC + i == v ? 1.0f : 0.0f);
+      row[c] = *reinterpret_cast<const uint4*>(e);
+    }
+  }
 }
 
 template <typename T> __global__ void convert_kernel(const float* __restrict__ in, T* __restrict__ out, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = from_f32<T>(in[i]);
-}
-
-template <typename T> __global__ void onehot_kernel(const int* __restrict__ tok, long n, int Vp, T* __restrict__ out) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n * Vp; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / Vp;
-    const int v = (int)(i % Vp);
-    out[i] = from_f32<T>(tok[r] == v ? 1.0f : 0.0f);
-  }
 }
 
 // ---- encoder head: reparameterisation + KL (vae_model.py:232-236) ---------------------------------

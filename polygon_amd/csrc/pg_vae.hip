@@ -338,8 +338,9 @@ static int encoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
   const TrainWs w = train_ws_layout(d, dtype, B, Ne, Ne);
   PG_REQUIRE(ws_bytes >= w.total, "encoder_fwd: workspace too small (%zu < %zu)", ws_bytes, w.total);
   const int Hq = d->Hq, Dz = d->Dz;
-  hipLaunchKernelGGL(build_packed_kernel, dim3(se.T, cdiv(B, 256)), dim3(256), 0, st, d_tokens, B, Tmax, d->pad, se, 0,
-                     at<int>(ws, w.enc_tok), (int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr);
+  hipLaunchKernelGGL(build_packed_kernel<T>, dim3(se.T, cdiv(B, 256)), dim3(256), 0, st, d_tokens, B, Tmax, d->pad, se, 0,
+                     at<int>(ws, w.enc_tok), (int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr,
+                     save ? at<T>(ws, w.e_onehot) : (T*)nullptr, vpad(d));
   PG_CHECK_LAUNCH();
   float* scal = at<float>(ws, w.scalars);
   PG_CHECK_HIP(hipMemsetAsync(scal + SC_KL_SUM, 0, 2 * sizeof(float), st));
@@ -493,9 +494,9 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
   PG_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "decoder_fwd: dropout %f outside [0,1)", p_drop);
   const int Hd = d->Hd, Dz = d->Dz, L = d->L, Vp = vpad(d);
   const int b_mul = dp ? dp->b_mul : 1, b_add = dp ? dp->b_add : 0;
-  hipLaunchKernelGGL(build_packed_kernel, dim3(sd.T, cdiv(B, 256)), dim3(256), 0, st, d_tokens, B, Tmax, d->pad, sd, 1,
+  hipLaunchKernelGGL(build_packed_kernel<T>, dim3(sd.T, cdiv(B, 256)), dim3(256), 0, st, d_tokens, B, Tmax, d->pad, sd, 1,
                      at<int>(ws, w.dec_tok), at<int>(ws, w.dec_tgt), at<int>(ws, w.dec_t), at<int>(ws, w.dec_b),
-                     at<int>(ws, w.dec_off));
+                     at<int>(ws, w.dec_off), save ? at<T>(ws, w.b_onehot) : (T*)nullptr, Vp);
   PG_CHECK_LAUNCH();
   float* scal = at<float>(ws, w.scalars);
   PG_CHECK_HIP(hipMemsetAsync(scal + SC_CE_SUM, 0, 2 * sizeof(float), st));
@@ -740,16 +741,10 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   PG_CHECK_LAUNCH();
   T* dh0_op = at<T>(ws, w.b_dh0_op);
   if (!persist) PG_TRY(convert_to<T>(dh0, dh0_op, (long)B * Hd, st));
-  {
-    GemmEpi<T> e;
-    e.C32 = dz; e.ldc = Dz;
-    PG_TRY(launch_gemm_nt<T>(dzp_op, 3 * Hd, at<T>(shadow, so.wih0zT), 3 * Hd, B, Dz, 3 * Hd, e, st));
-  }
-  {
-    GemmEpi<T> e;
-    e.C32 = dz; e.ldc = Dz; e.accumulate = 1;
-    PG_TRY(launch_gemm_nt<T>(dh0_op, Hd, at<T>(shadow, so.lat_wT), Hd, B, Dz, Hd, e, st));
-  }
+  // (K split over blocks: 8 output tiles with K = 1536 / 512 were 38 + 32 us of latency chain in front of the encoder BPTT)
+  PG_CHECK_HIP(hipMemsetAsync(dz, 0, (size_t)B * Dz * sizeof(float), st));
+  PG_TRY(launch_gemm_nt_splitk<T>(dzp_op, 3 * Hd, at<T>(shadow, so.wih0zT), 3 * Hd, B, Dz, 3 * Hd, dz, Dz, 1.0f, st));
+  PG_TRY(launch_gemm_nt_splitk<T>(dh0_op, Hd, at<T>(shadow, so.lat_wT), Hd, B, Dz, Hd, dz, Dz, 1.0f, st));
   // The large weight-gradient GEMMs need nothing but the recurrence's outputs.  With deferral on they go to the side
   // stream, forked BEHIND the dz chain above, and run beside pg_encoder_bwd (the encoder BPTT is a latency-bound kernel
   // on a quarter of the CUs); with deferral off they run here, in stream order.  Forked right behind the recurrence
@@ -757,6 +752,12 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   // blocks is several times the idle one): the encoder BPTT then started 420 us later than it could.
   hipStream_t sg_big = st;
   PG_TRY(defer_fork(st, &sg_big));
+  // The five large GEMMs alternate between the two side streams: one of them alone keeps the chip at ~30 % of the MFMA peak
+  // (its split-K epilogue is a quarter of its time, and a block's loads are exposed at three blocks per CU); two in flight
+  // fill each other's gaps.
+  const bool two = sg_big != st && !getenv("PG_TAIL_ONE_STREAM");
+  int nbig = 0;
+  auto big_stream = [&]() { return (two && (nbig++ & 1)) ? g_side2 : sg_big; };
   hipStream_t sg = sg_big;
   PG_TRY(launch_gemm_tn<T>(dlog, Vp, top, Hd, V, Hd, (int)Nd, grads + po.fc_w, Hd, 1.0f, s_ce, sg, grads + po.fc_b));   // decoder_fc
   for (int l = L - 1; l >= 0; --l) {
@@ -764,10 +765,10 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
     T* dGH = at<T>(ws, w.b_dGH_l[l]);
     // weight gradients of the layer, batched over all packed rows; the bias gradients (column sums of dGH / dGI) ride along
     PG_TRY(launch_gemm_tn<T>(dGH, 3 * Hd, at<T>(ws, w.d_sv[l][4]), Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_whh[l], Hd, 1.0f,
-                             nullptr, sg, grads + po.dec_bhh[l]));
+                             nullptr, big_stream(), grads + po.dec_bhh[l]));
     if (l > 0) {
       const T* X = drop ? at<T>(ws, w.d_hdrop[l - 1]) : at<T>(ws, w.d_hseq[l - 1]);
-      PG_TRY(launch_gemm_tn<T>(dGI, 3 * Hd, X, Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_wih[l], Hd, 1.0f, nullptr, sg,
+      PG_TRY(launch_gemm_tn<T>(dGI, 3 * Hd, X, Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_wih[l], Hd, 1.0f, nullptr, big_stream(),
                                grads + po.dec_bih[l]));
     }
   }
@@ -777,10 +778,8 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   {
     hipStream_t sg = defer_second(sg_big, st);
     // layer 0 input = [x_emb[token] ; z]: token half through the gather table, z half per sequence
-    T* oh = at<T>(ws, w.b_onehot);
+    T* oh = at<T>(ws, w.b_onehot);   // built by the forward pass (build_packed_kernel)
     float* dT = at<float>(ws, w.b_dT);
-    hipLaunchKernelGGL(onehot_kernel<T>, dim3(ew_blocks(Nd * Vp)), dim3(256), 0, sg, at<int>(ws, w.dec_tok), Nd, Vp, oh);
-    PG_CHECK_LAUNCH();
     PG_CHECK_HIP(hipMemsetAsync(dT, 0, (size_t)Vp * 3 * Hd * 4, sg));
     PG_TRY(launch_gemm_tn<T>(oh, Vp, dGI0, 3 * Hd, Vp, 3 * Hd, (int)Nd, dT, 3 * Hd, 1.0f, nullptr, sg, nullptr,
                              grads + po.dec_bih[0]));
@@ -873,18 +872,25 @@ static int encoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
     a.dhz_out = at<float>(ws, w.b_dhz[t & 1]);
     PG_TRY(launch_gru_bwd<T>(a, st));
   }
+  // The embedding-table tail (one-hot^T . dGI, then two small GEMMs) feeds nothing downstream: with deferral on it goes to
+  // the second side stream, beside the W_hh gradient below, instead of queueing behind it on the caller's stream.  Own
+  // one-hot / table-gradient scratch and atomic accumulation into x_emb's gradient: the decoder's deferred tail may still
+  // be running there.
+  hipStream_t se2 = st;
+  if (g_defer && g_defer_pending && g_side2) {
+    PG_CHECK_HIP(hipEventRecord(g_ev_fork, st));
+    PG_CHECK_HIP(hipStreamWaitEvent(g_side2, g_ev_fork, 0));
+    se2 = g_side2;
+  }
+  T* oh = at<T>(ws, w.e_onehot);     // built by the forward pass (build_packed_kernel)
+  float* dT = at<float>(ws, w.e_dT);
+  PG_CHECK_HIP(hipMemsetAsync(dT, 0, (size_t)Vp * 3 * Hq * 4, se2));
+  PG_TRY(launch_gemm_tn<T>(oh, Vp, dGI, 3 * Hq, Vp, 3 * Hq, (int)Ne, dT, 3 * Hq, 1.0f, nullptr, se2, nullptr, grads + po.enc_bih));
+  PG_TRY(small_gemm(dT, 3 * Hq, 1, params + po.enc_wih, E, 1, V, E, 3 * Hq, grads + po.x_emb, E, d->pad, se2));
+  PG_TRY(small_gemm(dT, 1, 3 * Hq, params + po.x_emb, E, 1, 3 * Hq, E, V, grads + po.enc_wih, E, -1, se2));
+  if (se2 != st) PG_CHECK_HIP(hipEventRecord(g_ev_join2, g_side2));   // the joins below and later wait for this newer record
   PG_TRY(launch_gemm_tn<T>(dGH, 3 * Hq, at<T>(ws, w.e_sv[4]), Hq, 3 * Hq, Hq, (int)Ne, grads + po.enc_whh, Hq, 1.0f, nullptr, st,
                            grads + po.enc_bhh));
-  // (own one-hot / table-gradient scratch and atomic accumulation into x_emb's gradient: the decoder's deferred tail may
-  // still be running on the side stream)
-  T* oh = at<T>(ws, w.e_onehot);
-  float* dT = at<float>(ws, w.e_dT);
-  hipLaunchKernelGGL(onehot_kernel<T>, dim3(ew_blocks(Ne * Vp)), dim3(256), 0, st, at<int>(ws, w.enc_tok), Ne, Vp, oh);
-  PG_CHECK_LAUNCH();
-  PG_CHECK_HIP(hipMemsetAsync(dT, 0, (size_t)Vp * 3 * Hq * 4, st));
-  PG_TRY(launch_gemm_tn<T>(oh, Vp, dGI, 3 * Hq, Vp, 3 * Hq, (int)Ne, dT, 3 * Hq, 1.0f, nullptr, st, nullptr, grads + po.enc_bih));
-  PG_TRY(small_gemm(dT, 3 * Hq, 1, params + po.enc_wih, E, 1, V, E, 3 * Hq, grads + po.x_emb, E, d->pad, st));
-  PG_TRY(small_gemm(dT, 1, 3 * Hq, params + po.x_emb, E, 1, 3 * Hq, E, V, grads + po.enc_wih, E, -1, st));
   PG_TRY(defer_join(st, false));   // the decoder's deferred weight gradients: complete in stream order from here on
   return PG_OK;
 }
