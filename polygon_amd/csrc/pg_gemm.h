@@ -31,7 +31,13 @@ int launch_gemm_nt(const T* A, long lda, const T* B, long ldb, int M, int N, int
 // chunks the kernel stages anyway - no second pass over the operand.
 template <typename T>
 int launch_gemm_tn(const T* A, long lda, const T* B, long ldb, int M, int N, int R, float* C, long ldc, float alpha,
-                   const float* alpha_dev, hipStream_t stream, float* colsum_a = nullptr, float* colsum_b = nullptr);
+                   const float* alpha_dev, hipStream_t stream, float* colsum_a = nullptr, float* colsum_b = nullptr,
+                   float* partial = nullptr, size_t partial_bytes = 0);
+// partial (optional, partial_bytes): scratch for a two-stage split-K reduction - every K split stores its tiles there with
+// plain stores and a second kernel sums them into C - used when it is large enough (PG_TN_SLAB_BYTES covers every shape
+// the launcher produces) and the output has enough tiles for the atomics to matter; C is then read-modify-written by the
+// reduction kernel in stream order, so no other stream may add to the same C region meanwhile.
+constexpr size_t PG_TN_SLAB_BYTES = (size_t)776 * 128 * 128 * sizeof(float);   // 768 split-K blocks, rounded up to whole XCD rounds
 
 // C[M,N] (fp32, ldc) += alpha * A[M,K] . B[N,K]^T, K split over blocks (atomic accumulation into an initialised C): for
 // outputs of a few tiles with a long K, where one block per tile is a latency chain.

@@ -131,6 +131,7 @@ struct TrainWs {
   // backward
   size_t b_dGI_l[PG_MAX_LAYERS], b_dGH_l[PG_MAX_LAYERS], b_dhz_l[PG_MAX_LAYERS][2];
   size_t b_dout, b_dGI, b_dGH, b_dhz[2], b_dh0, b_dh0_op, b_dzproj, b_dzproj_op, b_onehot, b_dT, e_onehot, e_dT, b_dq, b_dq_op, b_dhfin;
+  size_t b_slab[2];   // split-K slabs of the large weight-gradient GEMMs, one per side stream (PG_TN_SLAB_BYTES, pg_gemm.h)
   size_t total;
 };
 
@@ -175,6 +176,7 @@ static inline TrainWs train_ws_layout(const pg_dims* d, int dtype, long B, long 
   // the encoder's own copies: its embedding-gradient tail runs beside the decoder's deferred one (pg_vae.hip)
   w.e_onehot = take(Ne * Vp * es); w.e_dT = take(Vp * 3 * Hq * 4);
   w.b_dq = take(B * 2 * Dz * 4); w.b_dq_op = take(B * 2 * Dz * es); w.b_dhfin = take(B * Hq * 4);
+  w.b_slab[0] = take((size_t)776 * 128 * 128 * 4); w.b_slab[1] = take((size_t)776 * 128 * 128 * 4);
   w.total = p;
   return w;
 }

@@ -757,19 +757,27 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   // fill each other's gaps.
   const bool two = sg_big != st && !getenv("PG_TAIL_ONE_STREAM");
   int nbig = 0;
-  auto big_stream = [&]() { return (two && (nbig++ & 1)) ? g_side2 : sg_big; };
+  // (each stream has its own slab buffer for the two-stage split-K reduction of these GEMMs)
+  int which = 0;
+  auto big_stream = [&]() { which = (two && (nbig++ & 1)) ? 1 : 0; return which ? g_side2 : sg_big; };
+  const bool slabs = !getenv("PG_TN_ATOMIC");
   hipStream_t sg = sg_big;
   PG_TRY(launch_gemm_tn<T>(dlog, Vp, top, Hd, V, Hd, (int)Nd, grads + po.fc_w, Hd, 1.0f, s_ce, sg, grads + po.fc_b));   // decoder_fc
   for (int l = L - 1; l >= 0; --l) {
     T* dGI = at<T>(ws, w.b_dGI_l[l]);
     T* dGH = at<T>(ws, w.b_dGH_l[l]);
     // weight gradients of the layer, batched over all packed rows; the bias gradients (column sums of dGH / dGI) ride along
-    PG_TRY(launch_gemm_tn<T>(dGH, 3 * Hd, at<T>(ws, w.d_sv[l][4]), Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_whh[l], Hd, 1.0f,
-                             nullptr, big_stream(), grads + po.dec_bhh[l]));
+    {
+      hipStream_t sb = big_stream();
+      PG_TRY(launch_gemm_tn<T>(dGH, 3 * Hd, at<T>(ws, w.d_sv[l][4]), Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_whh[l], Hd, 1.0f,
+                               nullptr, sb, grads + po.dec_bhh[l], nullptr, slabs ? at<float>(ws, w.b_slab[which]) : nullptr,
+                               PG_TN_SLAB_BYTES));
+    }
     if (l > 0) {
       const T* X = drop ? at<T>(ws, w.d_hdrop[l - 1]) : at<T>(ws, w.d_hseq[l - 1]);
-      PG_TRY(launch_gemm_tn<T>(dGI, 3 * Hd, X, Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_wih[l], Hd, 1.0f, nullptr, big_stream(),
-                               grads + po.dec_bih[l]));
+      hipStream_t sb = big_stream();
+      PG_TRY(launch_gemm_tn<T>(dGI, 3 * Hd, X, Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_wih[l], Hd, 1.0f, nullptr, sb,
+                               grads + po.dec_bih[l], nullptr, slabs ? at<float>(ws, w.b_slab[which]) : nullptr, PG_TN_SLAB_BYTES));
     }
   }
   // ---- the small weight gradients feed nothing downstream: on a second side stream when deferring - a string of
