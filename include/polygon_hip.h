@@ -160,6 +160,12 @@ PG_API int pg_gemm_nt(int dtype, const void* A, long lda, const void* B, long ld
                       float* C32, void* Ct, long ldc, int accumulate, float alpha, void* stream);
 PG_API int pg_gemm_tn(int dtype, const void* A, long lda, const void* B, long ldb, int M, int N, int R, float* C, long ldc,
                       float alpha, void* stream);
+/* pg_gemm_tn_ws: the same with what the training step passes: colsum_a[M] / colsum_b[N] (nullable) += alpha * column sums
+ * of A / B (bias gradients), and a slab buffer (nullable; PG_TN_SLAB_BYTES of pg_gemm.h covers every shape) that switches
+ * large outputs to the two-stage split-K reduction and, in bf16 with M and N multiples of 256, to the 256 x 256 LDS-DMA
+ * kernel. */
+PG_API int pg_gemm_tn_ws(int dtype, const void* A, long lda, const void* B, long ldb, int M, int N, int R, float* C, long ldc,
+                         float alpha, float* colsum_a, float* colsum_b, float* slab, size_t slab_bytes, void* stream);
 
 /* pg_bench_gru: launches one recurrent step kernel (which = 0 forward cell, 1 backward cell) `repeat` times on
  * scratch operands carved from ws (>= 64*rows*H bytes + 16*H*H bytes): used by bench.py to time the dominant kernel

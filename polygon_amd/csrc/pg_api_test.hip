@@ -24,6 +24,20 @@ extern "C" int pg_gemm_tn(int dtype, const void* A, long lda, const void* B, lon
   PG_FAIL(PG_ERR_ARG, "pg_gemm_tn: bad dtype %d", dtype);
 }
 
+// pg_gemm_tn with the options the training step uses: fused column sums and a slab buffer for the two-stage split-K
+// reduction (large bf16 outputs then take the 256 x 256 LDS-DMA kernel)
+extern "C" int pg_gemm_tn_ws(int dtype, const void* A, long lda, const void* B, long ldb, int M, int N, int R, float* C,
+                             long ldc, float alpha, float* colsum_a, float* colsum_b, float* slab, size_t slab_bytes,
+                             void* stream) {
+  if (dtype == PG_F32)
+    return launch_gemm_tn<float>((const float*)A, lda, (const float*)B, ldb, M, N, R, C, ldc, alpha, nullptr, (hipStream_t)stream,
+                                 colsum_a, colsum_b, slab, slab_bytes);
+  if (dtype == PG_BF16)
+    return launch_gemm_tn<bf16_t>((const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, R, C, ldc, alpha, nullptr,
+                                  (hipStream_t)stream, colsum_a, colsum_b, slab, slab_bytes);
+  PG_FAIL(PG_ERR_ARG, "pg_gemm_tn_ws: bad dtype %d", dtype);
+}
+
 // ---- step-kernel micro-benchmark hook (development / roofline measurement) --------------------------
 #include <stdlib.h>
 #include "pg_gru.h"

@@ -1,5 +1,6 @@
 // Batched GEMM kernels (NT and TN forms) on the gfx950 MFMA tile engines.
 #include <stdlib.h>
+#include <type_traits>
 #include "pg_gemm.h"
 #include "pg_mma.h"
 
@@ -189,6 +190,157 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_tn_kernel(const typename C
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight-gradient GEMM, large form (bf16, M and N multiples of 256): C[m, n] += sum_r A[r, m] B[r, n] with 256 x 256 output
+// tiles, ONE 8-wave workgroup per CU, operands streamed by LDS-DMA through a 4-stage ring of 32-row tiles.
+// Why: at 128 x 128 tiles a block moves 16 KB per 1 MFLOP (64 flop/B) and the measured L2->CU intake of a computing CU
+// (~48 GB/s) caps the chip near 0.7 PFLOP/s whatever the occupancy; 256 x 256 tiles need half the bytes per flop.  The
+// register-staged engine above cannot hold such a tile with enough blocks per CU to hide its loads; here the loads need no
+// registers (LDS-DMA), three tiles (96 KB) are in flight per CU behind counted vmcnt waits, and the 128 accumulator registers
+// per lane leave room for double-buffered fragments at two waves per SIMD.
+// LDS image of an operand tile: [32 rows k][256 columns] bf16, rows unpadded (a DMA instruction is lane-linear: 64 lanes x
+// 16 B = two whole rows), 16-byte chunk c of row k stored at position c ^ ((k & 3) << 2): the four consecutive k rows that
+// one ds_read_b64_tr_b16 group touches then fall into four different bank quarters (conflict-free, checked by hand against
+// the instruction's 2 x 32 lane groups).  The swizzle is applied on the SOURCE side: lane p of row k fetches chunk
+// p ^ ((k & 3) << 2).  Rows beyond the split's range are fetched from a page of zeros (static counts of DMA instructions).
+// Output: always the two-stage split-K form (slabs + tn_reduce_kernel).  Column sums (bias gradients) are taken from the
+// LDS image by the tiles of the first tile column / row.
+namespace tn256 {
+constexpr int BM = 256, BN = 256, BKR = 32, NST = 4, NT = 512;
+constexpr int ROWB = 512, OP_BYTES = BKR * ROWB, STAGE = 2 * OP_BYTES, SMEM = NST * STAGE;
+static __device__ __attribute__((aligned(256))) unsigned char zero_page[512];   // never written: zero-initialised
+
+__device__ __forceinline__ uint4 frag(const char* s, int kbase, int mbase, int lane) {
+  // TnFrag<bf16_t>::load on the swizzled image
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const int k = kbase + 8 * (g >> 1) + q;
+  const int m = mbase + 16 * (g & 1) + 4 * p;
+  typedef __attribute__((address_space(3))) s16x4* lptr;
+  const char* a0 = s + k * ROWB + ((((m >> 3) ^ (q << 2))) << 4) + (m & 7) * 2;
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(a0 + 4 * ROWB));
+  uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+  return make_uint4(l2.x, l2.y, h2.x, h2.y);
+}
+}  // namespace tn256
+
+__global__ __launch_bounds__(tn256::NT) void gemm_tn256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
+                                                               long ldb, int M, int N, int R, int rows_per_split, int nsplits,
+                                                               float* __restrict__ partial, float alpha, float* colsum_a,
+                                                               float* colsum_b) {
+  using namespace tn256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles_n = N / BN, tiles = (M / BM) * tiles_n;
+  // XCD-aware map (workgroups go round-robin over the 8 XCDs, each with its own L2): all tiles of a split on ONE XCD, so
+  // that the split's rows of A and B cross the fabric once and the 2 / 6 re-reads by the other tiles are L2 hits
+  const int spx = (nsplits + 7) / 8;   // splits per XCD
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int split = xcd * spx + slot / tiles, tile = slot % tiles;
+  if (split >= nsplits) return;
+  const int bm = tile / tiles_n, bn = tile % tiles_n;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int r0 = split * rows_per_split, r1 = min(R, r0 + rows_per_split);
+  const int nk = (r1 - r0 + BKR - 1) / BKR;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;   // wave tile: 128 rows (m) x 64 columns (n)
+  f32x16 acc[4][2];
+  {
+    const f32x16 zacc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = zacc;
+  }
+  const bool csa = colsum_a != nullptr && bn == 0, csb = colsum_b != nullptr && bm == 0;   // block-uniform
+  float csA = 0.0f, csB = 0.0f;   // this thread's column (tid & 255) over the rows of its half (tid >> 8) of every tile
+
+  // four DMA instructions per wave and tile: instruction i = wave + 8 j covers rows 2i', 2i'+1 of A (i < 16) or B
+  auto issue = [&](int kt) __attribute__((always_inline)) {
+    char* st = smem + (kt & (NST - 1)) * STAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = wave + 8 * j;                 // wave-uniform; j < 2: A, j >= 2: B
+      const bool isA = j < 2;
+      const int pair = isA ? i : i - 16;
+      const int row = 2 * pair + (lane >> 5), pos = lane & 31;
+      const int c = pos ^ ((row & 3) << 2);
+      const long grow = (long)r0 + (long)kt * BKR + row;
+      const bf16_t* src = isA ? A + grow * lda + m0 + c * 8 : B + grow * ldb + n0 + c * 8;
+      const void* s2 = grow < r1 ? (const void*)src : (const void*)(zero_page + pos * 16);
+      pg_lds_dma16(s2, st + (isA ? 0 : OP_BYTES) + pair * 2 * ROWB);
+    }
+  };
+  auto wait_tiles = [&](int younger) __attribute__((always_inline)) {   // all but the DMA of `younger` later tiles
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  // hipcc must know that nothing it tracks is in flight when the loop starts (the DMA is invisible to it)
+  __builtin_amdgcn_s_waitcnt(0);
+  for (int p = 0; p < NST - 1; ++p)
+    if (p < nk) issue(p);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int younger = nk - 1 - kt;
+    wait_tiles(younger);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NST - 1 < nk) issue(kt + NST - 1);   // into the slot of tile kt-1, which every wave has left (barrier)
+    const char* sa = smem + (kt & (NST - 1)) * STAGE;
+    const char* sb = sa + OP_BYTES;
+    uint4 fa[2][4], fb[2][2];
+    auto lfrag = [&](int s, int set) __attribute__((always_inline)) {
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) fa[set][tm] = frag(sa, s * 16, wm * 128 + tm * 32, lane);
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) fb[set][tn] = frag(sb, s * 16, wn * 64 + tn * 32, lane);
+    };
+    lfrag(0, 0);
+#pragma unroll
+    for (int s = 0; s < BKR / 16; ++s) {
+      if (s + 1 < BKR / 16) lfrag(s + 1, (s + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) MmaOp<bf16_t>::run(acc[tm][tn], fa[s & 1][tm], fb[s & 1][tn]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (csa || csb) {   // block-uniform
+      const int m = tid & 255, h = tid >> 8;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int k = h * 16 + kk;
+        const int o = k * ROWB + (((m >> 3) ^ ((k & 3) << 2)) << 4) + (m & 7) * 2;
+        if (csa) csA += __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(sa + o) << 16);
+        if (csb) csB += __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(sb + o) << 16);
+      }
+    }
+  }
+  // ---- column sums: the two halves of a column through LDS, one atomic per column
+  __syncthreads();
+  if (csa || csb) {
+    float* xs = reinterpret_cast<float*>(smem);
+    xs[tid] = csA;
+    xs[NT + tid] = csB;
+    __syncthreads();
+    if (tid < 256) {
+      if (csa) atomicAdd(colsum_a + m0 + tid, (xs[tid] + xs[tid + 256]) * alpha);
+      if (csb) atomicAdd(colsum_b + n0 + tid, (xs[NT + tid] + xs[NT + tid + 256]) * alpha);
+    }
+  }
+  // ---- this split's tile as a slab (tn_reduce_kernel<256, 256> sums the slabs into C)
+  float* P = partial + ((long)split * tiles + tile) * (BM * BN);
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int ml = wm * 128 + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) P[ml * BN + wn * 64 + tn * 32 + (lane & 31)] = acc[tm][tn][reg];
+    }
+}
+
 // C[m, n] += alpha * sum over splits of the slabs written by gemm_tn_kernel; one thread per 4 columns of one tile row
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ partial, int nsplits, int tiles, int tiles_n,
@@ -311,6 +463,28 @@ int launch_gemm_tn(const T* A, long lda, const T* B, long ldb, int M, int N, int
   // blocks 133 us; 32-row tiles (40 KB of LDS: three blocks per CU), two tiles in flight, 768 blocks 108 us; deeper rings
   // and 256-wide tiles are slower (registers / LDS cut the blocks per CU).  Few output tiles: fewer split-K blocks, whose
   // fp32 atomics otherwise dominate (768 x 256: 48 us at 384 blocks, 59 us at 768).
+  if constexpr (std::is_same<T, bf16_t>::value) {
+    // large outputs: 256 x 256 tiles, one workgroup per CU, LDS-DMA ring (gemm_tn256_kernel); 192 blocks leave 64 CUs to
+    // the encoder BPTT that runs beside these GEMMs in the training step
+    static const int tn256 = getenv("PG_TN256") ? atoi(getenv("PG_TN256")) : 1;
+    if (tn256 && partial && !alpha_dev && M % 256 == 0 && N % 256 == 0 && (M / 256) * (N / 256) >= 8) {
+      const int tiles = (M / 256) * (N / 256);
+      static const int blocks_env = getenv("PG_TN256_BLOCKS") ? atoi(getenv("PG_TN256_BLOCKS")) : 192;
+      int splits = max(1, blocks_env / tiles);
+      int rows_per_split = cdiv(cdiv(R, splits), 32) * 32;
+      splits = cdiv(R, rows_per_split);
+      if ((size_t)splits * tiles * 256 * 256 * sizeof(float) <= partial_bytes) {
+        PG_LAUNCH_BIG_SMEM(gemm_tn256_kernel, dim3(8 * cdiv(splits, 8) * tiles), dim3(tn256::NT), tn256::SMEM, stream, A, lda, B, ldb, M, N, R,
+                           rows_per_split, splits, partial, alpha, colsum_a, colsum_b);
+        PG_CHECK_LAUNCH();
+        const long threads = (long)tiles * 256 * (256 / 4);
+        hipLaunchKernelGGL((tn_reduce_kernel<256, 256>), dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, stream, partial, splits,
+                           tiles, N / 256, M, N, C, ldc, alpha, (const float*)nullptr);
+        PG_CHECK_LAUNCH();
+        return PG_OK;
+      }
+    }
+  }
   static const int tn_blocks_env = getenv("PG_TN_BLOCKS") ? atoi(getenv("PG_TN_BLOCKS")) : 0;   // tuning aids
   static const int tn_bkr = getenv("PG_TN_BKR") ? atoi(getenv("PG_TN_BKR")) : 32;
   static const int tn_depth = getenv("PG_TN_DEPTH") ? atoi(getenv("PG_TN_DEPTH")) : 2;

@@ -33,6 +33,14 @@ __device__ __forceinline__ uint4 pg_buf_load16(__amdgpu_buffer_rsrc_t r, unsigne
   return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+// LDS-DMA by inline asm: 16 bytes per lane from a per-lane global address, lane-linear at the wave-uniform LDS address
+// `dst`.  (The builtin form makes hipcc track the transfer and guard later LDS reads with waits of its own; issued from
+// asm the transfers are invisible to it and every wait is the kernel's own counted one.)
+__device__ __forceinline__ void pg_lds_dma16(const void* src, void* dst) {
+  const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)dst);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m) : "memory", "m0");
+}
+
 template <typename T> struct MmaOp;
 template <> struct MmaOp<bf16_t> {
   static __device__ __forceinline__ void run(f32x16& c, const uint4& a, const uint4& b) {

@@ -119,6 +119,11 @@ struct DecBwdPersist {
   bf16_t* dGH[PG_MAX_LAYERS] = {};            // packed [N, 3H] (published)
   float* carry[PG_MAX_LAYERS] = {};           // [B, H] z.dh carried to the previous step
   float* dh0[PG_MAX_LAYERS] = {};             // [B, H] per-layer gradient of h0 (summed by the launcher)
+  // bias gradients (nullable, fp32 [3H], accumulated atomically at the end of the launch): d b_hh[l] = column sums of dGH_l,
+  // d b_ih[l] = column sums of dGI_l - every lane keeps the running sums of the gate gradients it produces anyway, which
+  // takes these sums out of the weight-gradient GEMMs (their fused column sums cost the 256 x 256 kernel 60 % of its time)
+  float* dbhh[PG_MAX_LAYERS] = {};
+  float* dbih[PG_MAX_LAYERS] = {};
   int sv_lane = 0;                            // sv[l][0..3] are in lane order, as the forward kernel wrote them
   float p_drop = 0.0f;
   uint64_t seed = 0;

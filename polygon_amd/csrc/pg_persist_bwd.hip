@@ -148,6 +148,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
   unsigned* err = a.sync + SYNC_ERR;
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
+  f32x4 sdr = f32x4{0.f, 0.f, 0.f, 0.f}, sdz = sdr, sdnr = sdr, sdn = sdr;   // running sums for the bias gradients
   __syncthreads();
 
   for (int s = 0; s <= Tg; ++s) {
@@ -380,6 +381,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
           dr[e] = dn[e] * hn * r * (1.0f - r);
           dnr[e] = dn[e] * r;
           dhz[e] = dh[e] * z;
+          sdr[e] += dr[e]; sdz[e] += dz[e]; sdnr[e] += dnr[e]; sdn[e] += dn[e];
         }
         *reinterpret_cast<f32x4*>(carry + (long)b * H + u0) = f32x4{dhz[0], dhz[1], dhz[2], dhz[3]};
         // The published gate gradients leave through LDS: a lane holds 4 units of one row, so direct stores are 16 rows
@@ -426,6 +428,28 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
       __hip_atomic_fetch_add(cnt_own, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     PG_STAMP(7);
+  }
+  // ---- bias gradients: the 16 lanes that share this lane's units (one per sequence row of the tile) are summed, then one
+  // lane adds 4 units x 3 gates per array
+  if (a.dbhh[l] || a.dbih[l]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) {
+        sdr[e] += __shfl_xor(sdr[e], o, 16); sdz[e] += __shfl_xor(sdz[e], o, 16);
+        sdnr[e] += __shfl_xor(sdnr[e], o, 16); sdn[e] += __shfl_xor(sdn[e], o, 16);
+      }
+    if (lr == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (a.dbhh[l]) {
+          atomicAdd(a.dbhh[l] + u0 + e, sdr[e]); atomicAdd(a.dbhh[l] + H + u0 + e, sdz[e]); atomicAdd(a.dbhh[l] + 2 * H + u0 + e, sdnr[e]);
+        }
+        if (a.dbih[l]) {
+          atomicAdd(a.dbih[l] + u0 + e, sdr[e]); atomicAdd(a.dbih[l] + H + u0 + e, sdz[e]); atomicAdd(a.dbih[l] + 2 * H + u0 + e, sdn[e]);
+        }
+      }
+    }
   }
 }
 

@@ -674,6 +674,7 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
         for (int i = 0; i < 5; ++i) pa.sv[l][i] = at<T>(ws, w.d_sv[l][i]);
         pa.dGI[l] = at<T>(ws, w.b_dGI_l[l]); pa.dGH[l] = at<T>(ws, w.b_dGH_l[l]);
         pa.carry[l] = at<float>(ws, w.b_dhz_l[l][0]); pa.dh0[l] = at<float>(ws, w.b_dhz_l[l][1]);
+        pa.dbhh[l] = grads + po.dec_bhh[l]; pa.dbih[l] = grads + po.dec_bih[l];   // bias gradients: not from the GEMMs then
       }
       pa.dout = dout;
       pa.p_drop = p_drop; pa.seed = seed; pa.b_mul = b_mul; pa.b_add = b_add;
@@ -770,14 +771,15 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
     {
       hipStream_t sb = big_stream();
       PG_TRY(launch_gemm_tn<T>(dGH, 3 * Hd, at<T>(ws, w.d_sv[l][4]), Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_whh[l], Hd, 1.0f,
-                               nullptr, sb, grads + po.dec_bhh[l], nullptr, slabs ? at<float>(ws, w.b_slab[which]) : nullptr,
+                               nullptr, sb, persist ? nullptr : grads + po.dec_bhh[l], nullptr, slabs ? at<float>(ws, w.b_slab[which]) : nullptr,
                                PG_TN_SLAB_BYTES));
     }
     if (l > 0) {
       const T* X = drop ? at<T>(ws, w.d_hdrop[l - 1]) : at<T>(ws, w.d_hseq[l - 1]);
       hipStream_t sb = big_stream();
       PG_TRY(launch_gemm_tn<T>(dGI, 3 * Hd, X, Hd, 3 * Hd, Hd, (int)Nd, grads + po.dec_wih[l], Hd, 1.0f, nullptr, sb,
-                               grads + po.dec_bih[l], nullptr, slabs ? at<float>(ws, w.b_slab[which]) : nullptr, PG_TN_SLAB_BYTES));
+                               persist ? nullptr : grads + po.dec_bih[l], nullptr, slabs ? at<float>(ws, w.b_slab[which]) : nullptr,
+                               PG_TN_SLAB_BYTES));
     }
   }
   // ---- the small weight gradients feed nothing downstream: on a second side stream when deferring - a string of
@@ -790,7 +792,7 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
     float* dT = at<float>(ws, w.b_dT);
     PG_CHECK_HIP(hipMemsetAsync(dT, 0, (size_t)Vp * 3 * Hd * 4, sg));
     PG_TRY(launch_gemm_tn<T>(oh, Vp, dGI0, 3 * Hd, Vp, 3 * Hd, (int)Nd, dT, 3 * Hd, 1.0f, nullptr, sg, nullptr,
-                             grads + po.dec_bih[0]));
+                             persist ? nullptr : grads + po.dec_bih[0]));
     // d x_emb[v,e] += sum_g dT[v,g] W_ih0[g,e] ; d W_ih0[g,e] += sum_v dT[v,g] x_emb[v,e]
     PG_TRY(small_gemm(dT, 3 * Hd, 1, params + po.dec_wih[0], E + Dz, 1, V, E, 3 * Hd, grads + po.x_emb, E, d->pad, sg));
     PG_TRY(small_gemm(dT, 1, 3 * Hd, params + po.x_emb, E, 1, 3 * Hd, E, V, grads + po.dec_wih[0], E + Dz, -1, sg));
