@@ -203,8 +203,10 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void gemm_tn_kernel(const typename C
 // one ds_read_b64_tr_b16 group touches then fall into four different bank quarters (conflict-free, checked by hand against
 // the instruction's 2 x 32 lane groups).  The swizzle is applied on the SOURCE side: lane p of row k fetches chunk
 // p ^ ((k & 3) << 2).  Rows beyond the split's range are fetched from a page of zeros (static counts of DMA instructions).
-// Output: always the two-stage split-K form (slabs + tn_reduce_kernel).  Column sums (bias gradients) are taken from the
-// LDS image by the tiles of the first tile column / row.
+// Output: always the two-stage split-K form (slabs + tn_reduce_kernel).  No fused column sums: read from the LDS image they
+// cost the blocks that owed them 60 % more time (the whole kernel waits for its slowest block); the decoder's bias
+// gradients come out of the BPTT kernel instead (DecBwdPersist::dbhh), and a caller that wants column sums gets the
+// 128 x 128 engine.
 namespace tn256 {
 constexpr int BM = 256, BN = 256, BKR = 32, NST = 4, NT = 512;
 constexpr int ROWB = 512, OP_BYTES = BKR * ROWB, STAGE = 2 * OP_BYTES, SMEM = NST * STAGE;
@@ -226,8 +228,7 @@ __device__ __forceinline__ uint4 frag(const char* s, int kbase, int mbase, int l
 
 __global__ __launch_bounds__(tn256::NT) void gemm_tn256_kernel(const bf16_t* __restrict__ A, long lda, const bf16_t* __restrict__ B,
                                                                long ldb, int M, int N, int R, int rows_per_split, int nsplits,
-                                                               float* __restrict__ partial, float alpha, float* colsum_a,
-                                                               float* colsum_b) {
+                                                               float* __restrict__ partial) {
   using namespace tn256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = N / BN, tiles = (M / BM) * tiles_n;
@@ -252,8 +253,6 @@ __global__ __launch_bounds__(tn256::NT) void gemm_tn256_kernel(const bf16_t* __r
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][j] = zacc;
   }
-  const bool csa = colsum_a != nullptr && bn == 0, csb = colsum_b != nullptr && bm == 0;   // block-uniform
-  float csA = 0.0f, csB = 0.0f;   // this thread's column (tid & 255) over the rows of its half (tid >> 8) of every tile
 
   // four DMA instructions per wave and tile: instruction i = wave + 8 j covers rows 2i', 2i'+1 of A (i < 16) or B
   auto issue = [&](int kt) __attribute__((always_inline)) {
@@ -280,55 +279,70 @@ __global__ __launch_bounds__(tn256::NT) void gemm_tn256_kernel(const bf16_t* __r
   __builtin_amdgcn_s_waitcnt(0);
   for (int p = 0; p < NST - 1; ++p)
     if (p < nk) issue(p);
-  for (int kt = 0; kt < nk; ++kt) {
-    const int younger = nk - 1 - kt;
-    wait_tiles(younger);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (kt + NST - 1 < nk) issue(kt + NST - 1);   // into the slot of tile kt-1, which every wave has left (barrier)
+  // Software pipeline over the tiles: the barrier that hands over tile kt+1 sits BETWEEN the two k-steps of tile kt, so
+  // the fragments of (kt+1, step 0) are read while the MFMAs of (kt, step 1) run, and those of (kt, step 1) while the
+  // hand-over waits: no k-step waits for its own LDS reads.  (Left to itself hipcc hoists all 24 fragment reads of a
+  // tile in front of its 16 MFMAs and the wave idles for the LDS round trip once per tile.)
+  // (two named register sets, selected at compile time: an array indexed by a lambda parameter ended up in scratch)
+  uint4 fa0[4], fb0[2], fa1[4], fb1[2];
+  auto lfrag = [&](int kt, auto set_c) __attribute__((always_inline)) {   // set s holds the fragments of k-step s
+    constexpr int set = decltype(set_c)::value;
     const char* sa = smem + (kt & (NST - 1)) * STAGE;
     const char* sb = sa + OP_BYTES;
-    uint4 fa[2][4], fb[2][2];
-    auto lfrag = [&](int s, int set) __attribute__((always_inline)) {
 #pragma unroll
-      for (int tm = 0; tm < 4; ++tm) fa[set][tm] = frag(sa, s * 16, wm * 128 + tm * 32, lane);
+    for (int tm = 0; tm < 4; ++tm) (set ? fa1 : fa0)[tm] = frag(sa, set * 16, wm * 128 + tm * 32, lane);
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) fb[set][tn] = frag(sb, s * 16, wn * 64 + tn * 32, lane);
-    };
-    lfrag(0, 0);
+    for (int tn = 0; tn < 2; ++tn) (set ? fb1 : fb0)[tn] = frag(sb, set * 16, wn * 64 + tn * 32, lane);
+  };
+  auto mma_set = [&](auto set_c) __attribute__((always_inline)) {
+    constexpr int set = decltype(set_c)::value;
 #pragma unroll
-    for (int s = 0; s < BKR / 16; ++s) {
-      if (s + 1 < BKR / 16) lfrag(s + 1, (s + 1) & 1);
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) MmaOp<bf16_t>::run(acc[tm][tn], (set ? fa1 : fa0)[tm], (set ? fb1 : fb0)[tn]);
+  };
+  // the MFMAs of k-step `cur` with the fragment reads of (tile ktn, k-step 1 - cur) issued between them, two MFMAs then
+  // three reads at a time: measured alone the kernel's MFMAs take 81 us and its LDS reads 48 - back to back they do not
+  // overlap inside a wave, and the second wave of the SIMD is in the same phase (the tile barrier keeps them in step)
+  auto mma_and_read = [&](auto cur_c, int ktn) __attribute__((always_inline)) {
+    constexpr int cur = decltype(cur_c)::value, nxt = 1 - cur;
+    const char* sa = smem + (ktn & (NST - 1)) * STAGE;
+    const char* sb = sa + OP_BYTES;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      MmaOp<bf16_t>::run(acc[tm][0], (cur ? fa1 : fa0)[tm], (cur ? fb1 : fb0)[0]);
+      MmaOp<bf16_t>::run(acc[tm][1], (cur ? fa1 : fa0)[tm], (cur ? fb1 : fb0)[1]);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < 2; ++tn) MmaOp<bf16_t>::run(acc[tm][tn], fa[s & 1][tm], fb[s & 1][tn]);
+      (nxt ? fa1 : fa0)[tm] = frag(sa, nxt * 16, wm * 128 + tm * 32, lane);
+      if (tm < 2) (nxt ? fb1 : fb0)[tm] = frag(sb, nxt * 16, wn * 64 + tm * 32, lane);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (csa || csb) {   // block-uniform
-      const int m = tid & 255, h = tid >> 8;
-#pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int k = h * 16 + kk;
-        const int o = k * ROWB + (((m >> 3) ^ ((k & 3) << 2)) << 4) + (m & 7) * 2;
-        if (csa) csA += __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(sa + o) << 16);
-        if (csb) csB += __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(sb + o) << 16);
-      }
-    }
+  };
+  static_assert(BKR == 32, "two k-steps per tile");
+  wait_tiles(nk - 1);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  lfrag(0, IntC<0>{});
+  // Order inside a tile: the MFMAs of step 0 first (their fragments were read half a tile ago), THEN the 12 reads of step 1
+  // - read first, 24 LDS operations would be outstanding in front of the MFMAs, more than the 4-bit lgkmcnt can count, and
+  // hipcc falls back to lgkmcnt(0).  (Spreading the reads between the MFMAs with sched_group_barrier spilled.)
+#pragma unroll 1
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    __builtin_amdgcn_sched_barrier(0);
+    mma_and_read(IntC<0>{}, kt);          // k-step 0 of tile kt; reads k-step 1 of tile kt
+    // ---- hand-over of tile kt+1: this wave's DMA of it has landed, the barrier extends that to every wave's and proves
+    // that nobody reads tile kt-1 any more, whose slot the next request overwrites
+    wait_tiles(nk - 2 - kt < 1 ? nk - 2 - kt : 1);   // tiles requested after kt+1 so far: kt+2 at most
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    mma_and_read(IntC<1>{}, kt + 1);      // k-step 1 of tile kt; reads k-step 0 of tile kt+1
+    // the next request goes out behind the MFMAs: its address arithmetic runs under them
+    if (kt + NST - 1 < nk) issue(kt + NST - 1);
   }
-  // ---- column sums: the two halves of a column through LDS, one atomic per column
-  __syncthreads();
-  if (csa || csb) {
-    float* xs = reinterpret_cast<float*>(smem);
-    xs[tid] = csA;
-    xs[NT + tid] = csB;
-    __syncthreads();
-    if (tid < 256) {
-      if (csa) atomicAdd(colsum_a + m0 + tid, (xs[tid] + xs[tid + 256]) * alpha);
-      if (csb) atomicAdd(colsum_b + n0 + tid, (xs[NT + tid] + xs[NT + tid + 256]) * alpha);
-    }
-  }
+  __builtin_amdgcn_sched_barrier(0);
+  mma_set(IntC<0>{});
+  lfrag(nk - 1, IntC<1>{});
+  mma_set(IntC<1>{});
   // ---- this split's tile as a slab (tn_reduce_kernel<256, 256> sums the slabs into C)
   float* P = partial + ((long)split * tiles + tile) * (BM * BN);
 #pragma unroll
@@ -467,7 +481,7 @@ int launch_gemm_tn(const T* A, long lda, const T* B, long ldb, int M, int N, int
     // large outputs: 256 x 256 tiles, one workgroup per CU, LDS-DMA ring (gemm_tn256_kernel); 192 blocks leave 64 CUs to
     // the encoder BPTT that runs beside these GEMMs in the training step
     static const int tn256 = getenv("PG_TN256") ? atoi(getenv("PG_TN256")) : 1;
-    if (tn256 && partial && !alpha_dev && M % 256 == 0 && N % 256 == 0 && (M / 256) * (N / 256) >= 8) {
+    if (tn256 && partial && !alpha_dev && !colsum_a && !colsum_b && M % 256 == 0 && N % 256 == 0 && (M / 256) * (N / 256) >= 8) {
       const int tiles = (M / 256) * (N / 256);
       static const int blocks_env = getenv("PG_TN256_BLOCKS") ? atoi(getenv("PG_TN256_BLOCKS")) : 192;
       int splits = max(1, blocks_env / tiles);
@@ -475,7 +489,7 @@ int launch_gemm_tn(const T* A, long lda, const T* B, long ldb, int M, int N, int
       splits = cdiv(R, rows_per_split);
       if ((size_t)splits * tiles * 256 * 256 * sizeof(float) <= partial_bytes) {
         PG_LAUNCH_BIG_SMEM(gemm_tn256_kernel, dim3(8 * cdiv(splits, 8) * tiles), dim3(tn256::NT), tn256::SMEM, stream, A, lda, B, ldb, M, N, R,
-                           rows_per_split, splits, partial, alpha, colsum_a, colsum_b);
+                           rows_per_split, splits, partial);
         PG_CHECK_LAUNCH();
         const long threads = (long)tiles * 256 * (256 / 4);
         hipLaunchKernelGGL((tn_reduce_kernel<256, 256>), dim3((unsigned)cdiv(threads, 256)), dim3(256), 0, stream, partial, splits,

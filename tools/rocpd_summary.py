@@ -68,7 +68,7 @@ def counters(dbs, out_json, note):
     """Per-kernel averages (per launch, summed over the device's shader engines as rocprofv3 reports them) of every counter
     found in the given --pmc result databases; kernels matched by the names of interest only."""
     tags = ("dec_sample_persist_kernel", "dec_bwd_persist_kernel", "dec_fwd_persist_kernel", "enc_bwd_persist_kernel", "enc_fwd_persist_kernel",
-            "gemm_tn_kernel", "gemm_nt_kernel", "ce_kernel", "adam_kernel")
+            "gemm_tn256_kernel", "tn_reduce_kernel", "gemm_tn_kernel", "gemm_nt_kernel", "fc_ce_kernel", "adam_kernel")
     out = {}
     for db in dbs:
         c = sqlite3.connect(db)
@@ -79,6 +79,7 @@ def counters(dbs, out_json, note):
                     e = out.setdefault(tag, {})
                     e[cname] = v
                     e["launches_" + cname] = n
+                    break
     for e in out.values():   # derived ratios (MI355X_MICROARCH.md counter table)
         if "SQ_WAVE_CYCLES" in e and e["SQ_WAVE_CYCLES"]:
             w = e["SQ_WAVE_CYCLES"]
