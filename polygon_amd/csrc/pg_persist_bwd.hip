@@ -79,10 +79,12 @@ __device__ __forceinline__ void wait_parts(int younger) {
   }
 }
 
-// development aid: workgroup (g 0, traced layer, slice 0) records wall-clock stamps (100 MHz) of its steps 8..15
+// development aid: workgroup (g 0, traced layer, slice 0) records wall-clock stamps (100 MHz) of its steps 8..15.  Stamps and
+// the knock-out switches (PG_PERSIST_DBG) live in the DBG instantiation only: as run-time tests they cost the production
+// kernel 6-8 scalar branches per part.
 #define PG_STAMP(slot)                                                                                   \
   do {                                                                                                   \
-    if (a.stamps && tid == 0 && g == 0 && c == 0 && l == (int)a.stamps[0] && s >= (int)a.stamps[1] && s < (int)a.stamps[1] + 8) \
+    if (DBG && a.stamps && tid == 0 && g == 0 && c == 0 && l == (int)a.stamps[0] && s >= (int)a.stamps[1] && s < (int)a.stamps[1] + 8) \
       a.stamps[8 + (s - (int)a.stamps[1]) * 8 + (slot)] = wall_clock64();                                               \
   } while (0)
 
@@ -99,9 +101,10 @@ template <int H, bool TOP> struct BwdGeo {
   static constexpr int SMEM = WN_BYTES + NSLOT * PART_BYTES + STG_BYTES + 16;
 };
 
-template <int H, bool TOP, int AUXL>
+template <int H, bool TOP, int AUXL, bool DBG>
 __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched& sd, int g, int l, int c, char* smem) {
   using G = BwdGeo<H, TOP>;
+  const int dbg = DBG ? a.dbg : 0;
   constexpr int NCU = G::NCU, ROWW = G::ROWW, NSLOT = G::NSLOT, D = G::D;
   static_assert(H == 512, "one LDS-DMA instruction (64 lanes x 16 B) must cover exactly 512 gate columns of one row");
   static_assert(D <= 6, "wait_parts covers at most 6 parts in flight");
@@ -188,7 +191,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
     // flattened part sequence of the step: tile-major, own parts before upper parts
     int qi = 0, ji = 0, pi = 0, si = 0;            // next part to issue: index, tile, part in tile, slot
     auto issue = [&]() __attribute__((always_inline)) {
-      if (qi < nparts && !(a.dbg & 1)) {           // block-uniform
+      if (qi < nparts && !(dbg & 1)) {           // block-uniform
         const bool own = has_own && pi < 3;
         const int sub = own ? pi : pi - (has_own ? 3 : 0);
         const bf16_t* base = (own ? own_base : up_base) + sub * 512;
@@ -216,7 +219,10 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
     // one part: wait for its DMAs, publish them, refill the slot freed by the previous part, 16 K-steps
     auto part_begin = [&]() __attribute__((always_inline)) -> const char* {
       const int younger = nparts - 1 - qc;
-      if (!(a.dbg & 1)) wait_parts(younger < D ? younger : D);
+      if (!(dbg & 1)) {
+        if (younger >= D) wait_parts(D);       // steady state: one compare, the immediate is a constant
+        else wait_parts(younger);
+      }
       // a bare s_barrier: __syncthreads() carries a workgroup release fence = vmcnt(0), which would drain the very DMAs
       // this pipeline keeps in flight.  Nothing but the DMA'd slot is communicated here (the wave's own LDS reads of the
       // previous part were consumed by its MFMAs), so the counted wait above is the only ordering needed.
@@ -236,8 +242,8 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
       // epilogue inputs of this lane's sequence, fetched under the tile's MFMAs
       f32x4 cr = f32x4{0.f, 0.f, 0.f, 0.f}, dtop = f32x4{0.f, 0.f, 0.f, 0.f};
       bf16x4 svr, svz, svn, svhn, svhp;
-      if (has_own && !(a.dbg & 4)) cr = *reinterpret_cast<const f32x4*>(carry + (long)bs * H + u0);
-      if (t >= 0 && !(a.dbg & 4)) {
+      if (has_own && !(dbg & 4)) cr = *reinterpret_cast<const f32x4*>(carry + (long)bs * H + u0);
+      if (t >= 0 && !(dbg & 4)) {
         const long sidx = (long)(o + bs) * H + u0;
         if constexpr (TOP) dtop = *reinterpret_cast<const f32x4*>(a.dout + sidx);
         // lane order, as the forward kernel wrote them (pg_persist.h, sv_tile_slot)
@@ -264,7 +270,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
           const char* A = part_begin();
-          if (a.dbg & 2) continue;
+          if (dbg & 2) continue;
           // the part's 16 activation fragments are read in groups of 4, two groups (8 reads, <= 0.5 us of MFMAs) ahead of
           // the MFMAs that consume them; the scheduling barriers keep hipcc from sinking the reads back to their uses
           bf16x8 f[4][4];
@@ -291,7 +297,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
             const char* A = part_begin();
-            if (a.dbg & 2) continue;
+            if (dbg & 2) continue;
             // the part's 16 activation fragments are read in groups of 4, two groups (8 reads, <= 0.5 us of MFMAs) ahead of
             // the MFMAs that consume them; the scheduling barriers keep hipcc from sinking the reads back to their uses
             bf16x8 f[4][4];
@@ -318,7 +324,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
           {
             const char* A = part_begin();
             const char* Wn = sWn + (wave * 16 + lr) * ROWW + ((lq ^ lr) & 3) * 16;   // chunk ks*4+lq of row lr sits at (ks*4+lq) ^ lr
-            if (!(a.dbg & 2)) {
+            if (!(dbg & 2)) {
             // activation and weight fragments both come from LDS here: groups of 4 K-steps, one group ahead
             bf16x8 xa[4], wa[4], xb[4], wb[4];
 #pragma unroll
@@ -371,7 +377,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
         if (live) *reinterpret_cast<f32x4*>(a.dh0[l] + (long)b * H + u0) = f32x4{dh[0], dh[1], dh[2], dh[3]};
         continue;
       }
-      if (live && !((a.dbg & 4) && dh[0] != 12345.678f)) {
+      if (live && !((dbg & 4) && dh[0] != 12345.678f)) {
         float dr[4], dz[4], dn[4], dnr[4], dhz[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -396,7 +402,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (!(a.dbg & 4)) {
+      if (!(dbg & 4)) {
         // 2 arrays x 3 gates x 16 rows x 8 segments = 768 segment stores, 3 per thread; array and gate are wave-uniform
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -453,15 +459,15 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
   }
 }
 
-template <int H, int AUXL>
+template <int H, int AUXL, bool DBG>
 __global__ __launch_bounds__(256) void dec_bwd_persist_kernel(DecBwdPersist a, Sched sd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NCU = H / 64;
   int g, li, c;   // blockIdx % 8 labels the XCD: a group's workgroups (or at least a layer's) share one
   if (!persist_map(blockIdx.x, a.NG, NCU, g, li, c)) return;
   const int l = a.L - 1 - li;                               // top layer first: it is the head of the dependency chain
-  if (l == a.L - 1) dec_bwd_body<H, true, AUXL>(a, sd, g, l, c, smem);
-  else dec_bwd_body<H, false, AUXL>(a, sd, g, l, c, smem);
+  if (l == a.L - 1) dec_bwd_body<H, true, AUXL, DBG>(a, sd, g, l, c, smem);
+  else dec_bwd_body<H, false, AUXL, DBG>(a, sd, g, l, c, smem);
 }
 
 // dh0 = sum over layers of the per-layer h0 gradients (every layer starts from the same decoder_lat(z))
@@ -495,13 +501,16 @@ int launch_dec_bwd_persist(DecBwdPersist& a, const Sched& sd, int H, float* dh0_
   a.stamps = persist_stamps_for(1);
   a.dbg = getenv("PG_PERSIST_DBG") ? atoi(getenv("PG_PERSIST_DBG")) : 0;
   PG_CHECK_HIP(hipMemsetAsync(a.sync, 0, PG_PERSIST_SYNC_WORDS * sizeof(unsigned), stream));
-  static bool attr_done = false;
-  if (!attr_done) {
-    PG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, AUX_SC1>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    PG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, 0>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    attr_done = true;
+  const bool dbgk = a.dbg != 0 || a.stamps != nullptr;
+  const bool plain = persist_dma_plain();
+  const void* kern = plain ? (dbgk ? reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, 0, true>)
+                                   : reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, 0, false>))
+                           : (dbgk ? reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, AUX_SC1, true>)
+                                   : reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, AUX_SC1, false>));
+  static bool attr_done[4] = {false, false, false, false};
+  if (!attr_done[plain * 2 + dbgk]) {
+    PG_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_done[plain * 2 + dbgk] = true;
   }
   const int grid = a.NG == 8 ? 8 * a.L * GL::NCU : 256;   // co-residency: one workgroup per CU (checked against the CU count by the forward launcher's rule)
   static int n_cu = 0;
@@ -511,10 +520,8 @@ int launch_dec_bwd_persist(DecBwdPersist& a, const Sched& sd, int H, float* dh0_
     PG_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
   }
   PG_REQUIRE(grid <= n_cu, "dec_bwd_persist: %d workgroups cannot be co-resident on %d CUs", grid, n_cu);
-  if (persist_dma_plain())
-    hipLaunchKernelGGL((dec_bwd_persist_kernel<512, 0>), dim3(grid), dim3(256), (size_t)SMEM, stream, a, sd);
-  else
-    hipLaunchKernelGGL((dec_bwd_persist_kernel<512, AUX_SC1>), dim3(grid), dim3(256), (size_t)SMEM, stream, a, sd);
+  void* kargs[] = {&a, const_cast<Sched*>(&sd)};
+  PG_CHECK_HIP(hipLaunchKernel(kern, dim3(grid), dim3(256), kargs, (size_t)SMEM, stream));
   PG_CHECK_LAUNCH();
   PG_TRY(persist_fail_mirror(stream));
   const long n = (long)a.B * H;

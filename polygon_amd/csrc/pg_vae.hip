@@ -732,27 +732,33 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
     PG_TRY(launch_gru_bwd_diag<T>(dg, st));
   }
   prof_end(1, pslot, st, sd.T + L, pflop);
-  // ---- the dz path: ALL the encoder BPTT waits for.  Stays on the caller's stream and is kept short: the row-segment sum
-  // of layer 0's dGI (the gradient of the per-sequence z projection), then dz = dzproj . W_ih0[:, E:] + dh0 . W_lat
+  // Order of the tail.  The large weight-gradient GEMMs need nothing but the recurrence's outputs; the dz chain (row-segment
+  // sum, two skinny GEMMs) is ALL the encoder BPTT waits for.  With deferral on the GEMMs go to the side streams and are
+  // forked FIRST, right behind the recurrence: as 192 one-per-CU workgroups they leave 64 CUs to the chain's small kernels
+  // (with the 128 x 128 engine's 768 resident blocks the chain ran 3x slower beside them and the fork sat behind it).
+  static const bool fork_late = getenv("PG_TAIL_FORK_LATE") != nullptr;   // A/B aid: the dz chain in front of the fork
+  hipStream_t sg_big = st;
+  if (!fork_late) PG_TRY(defer_fork(st, &sg_big));
+  const bool fork_early = sg_big != st;
   T* dGI0 = at<T>(ws, w.b_dGI_l[0]);
   float* dzp = at<float>(ws, w.b_dzproj);
   T* dzp_op = at<T>(ws, w.b_dzproj_op);
-  hipLaunchKernelGGL(rowseg_sum_kernel<T>, dim3(cdiv(3 * Hd, 64 * (16 / (int)sizeof(T))), cdiv(B, 4)), dim3(256), 0, st, dGI0,
-                     at<int>(ws, w.dec_off), sd.T, 3 * Hd, B, dzp, dzp_op);
-  PG_CHECK_LAUNCH();
   T* dh0_op = at<T>(ws, w.b_dh0_op);
-  if (!persist) PG_TRY(convert_to<T>(dh0, dh0_op, (long)B * Hd, st));
-  // (K split over blocks: 8 output tiles with K = 1536 / 512 were 38 + 32 us of latency chain in front of the encoder BPTT)
-  PG_CHECK_HIP(hipMemsetAsync(dz, 0, (size_t)B * Dz * sizeof(float), st));
-  PG_TRY(launch_gemm_nt_splitk<T>(dzp_op, 3 * Hd, at<T>(shadow, so.wih0zT), 3 * Hd, B, Dz, 3 * Hd, dz, Dz, 1.0f, st));
-  PG_TRY(launch_gemm_nt_splitk<T>(dh0_op, Hd, at<T>(shadow, so.lat_wT), Hd, B, Dz, Hd, dz, Dz, 1.0f, st));
-  // The large weight-gradient GEMMs need nothing but the recurrence's outputs.  With deferral on they go to the side
-  // stream, forked BEHIND the dz chain above, and run beside pg_encoder_bwd (the encoder BPTT is a latency-bound kernel
-  // on a quarter of the CUs); with deferral off they run here, in stream order.  Forked right behind the recurrence
-  // they made the dz chain 3x slower (its small kernels are latency-bound, and memory latency under 768 resident GEMM
-  // blocks is several times the idle one): the encoder BPTT then started 420 us later than it could.
-  hipStream_t sg_big = st;
-  PG_TRY(defer_fork(st, &sg_big));
+  auto dz_chain = [&]() -> int {
+    hipLaunchKernelGGL(rowseg_sum_kernel<T>, dim3(cdiv(3 * Hd, 64 * (16 / (int)sizeof(T))), cdiv(B, 4)), dim3(256), 0, st, dGI0,
+                       at<int>(ws, w.dec_off), sd.T, 3 * Hd, B, dzp, dzp_op);
+    PG_CHECK_LAUNCH();
+    if (!persist) PG_TRY(convert_to<T>(dh0, dh0_op, (long)B * Hd, st));
+    // (K split over blocks: 8 output tiles with K = 1536 / 512 were 38 + 32 us of latency chain in front of the encoder BPTT)
+    PG_CHECK_HIP(hipMemsetAsync(dz, 0, (size_t)B * Dz * sizeof(float), st));
+    PG_TRY(launch_gemm_nt_splitk<T>(dzp_op, 3 * Hd, at<T>(shadow, so.wih0zT), 3 * Hd, B, Dz, 3 * Hd, dz, Dz, 1.0f, st));
+    PG_TRY(launch_gemm_nt_splitk<T>(dh0_op, Hd, at<T>(shadow, so.lat_wT), Hd, B, Dz, Hd, dz, Dz, 1.0f, st));
+    return PG_OK;
+  };
+  if (!fork_early) {
+    PG_TRY(dz_chain());
+    PG_TRY(defer_fork(st, &sg_big));
+  }
   // The five large GEMMs alternate between the two side streams: one of them alone keeps the chip at ~30 % of the MFMA peak
   // (its split-K epilogue is a quarter of its time, and a block's loads are exposed at three blocks per CU); two in flight
   // fill each other's gaps.
@@ -781,6 +787,12 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
                                persist ? nullptr : grads + po.dec_bih[l], nullptr, slabs ? at<float>(ws, w.b_slab[which]) : nullptr,
                                PG_TN_SLAB_BYTES));
     }
+  }
+  if (fork_early) {
+    PG_TRY(dz_chain());
+    // the small gradients below read the chain's outputs: the second side stream waits for it
+    PG_CHECK_HIP(hipEventRecord(g_ev_fork, st));
+    PG_CHECK_HIP(hipStreamWaitEvent(g_side2, g_ev_fork, 0));
   }
   // ---- the small weight gradients feed nothing downstream: on a second side stream when deferring - a string of
   // latency-bound kernels (130 us) that overlaps the large GEMMs instead of queueing behind them - else here in order
