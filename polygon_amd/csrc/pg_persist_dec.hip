@@ -81,7 +81,7 @@ __device__ __forceinline__ bool wait_ge(unsigned* p, unsigned target, unsigned* 
 // development aid: workgroup (g 0, layer STAMP_L, slice 0) records wall-clock stamps (100 MHz) of steps 8..15, 8 slots each
 #define PG_STAMP(slot)                                                                                   \
   do {                                                                                                   \
-    if (a.stamps && tid == 0 && g == 0 && c == 0 && l == (int)a.stamps[0] && t >= (int)a.stamps[1] && t < (int)a.stamps[1] + 8) \
+    if (DBG && a.stamps && tid == 0 && g == 0 && c == 0 && l == (int)a.stamps[0] && t >= (int)a.stamps[1] && t < (int)a.stamps[1] + 8) \
       a.stamps[8 + (t - (int)a.stamps[1]) * 8 + (slot)] = wall_clock64();                                               \
   } while (0)
 
@@ -106,9 +106,15 @@ template <int H> struct DecGeo {
   static_assert(2 * TILE0_BYTES + TOK_BYTES <= STG_OFF, "layer-0 layout must fit in front of the staging block");
 };
 
-template <int H, bool L0, int AUXL>
+// LK: 0 = layer 0, 1 = a middle layer, 2 = the top layer.  DBG: stamps and the PG_PERSIST_DBG knock-out switches (as
+// run-time tests they cost the production kernel scalar branches in every tile).  FAST: the training configuration -
+// dropout between layers, activations saved in lane order - known at compile time, so that the tile loop has no
+// kernel-uniform branches and its store count is a constant.
+template <int H, int LK, int AUXL, bool DBG, bool FAST>
 __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched& sd, int g, int l, int c, char* smem) {
   using G = DecGeo<H>;
+  constexpr bool L0 = LK == 0;
+  const int dbg = DBG ? a.dbg : 0;
   constexpr int KS = G::KS, NCU = G::NCU, ROWW = G::ROWW;
   static_assert(H == 512, "one LDS-DMA instruction (64 lanes x 16 B) must cover exactly one row half");
   char* sWin = smem;
@@ -178,9 +184,11 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
   volatile unsigned* sFlagT = reinterpret_cast<volatile unsigned*>(smem + G::SMEM - 16);
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
-  const bool has_drop = hdrop != nullptr, has_sv = a.sv[l][0] != nullptr;     // kernel-uniform
+  const bool has_drop = FAST ? LK != 2 : hdrop != nullptr;                      // kernel-uniform
+  const bool has_sv = FAST ? true : a.sv[l][0] != nullptr;
+  const bool sv_lane = FAST ? true : a.sv_lane != 0;
   const int narr = 1 + (has_drop ? 1 : 0) + (has_sv ? 1 : 0);                   // row-major bf16 outputs: h, dropout(h), h_prev
-  const int NS = 1 + (narr > 2 ? 2 : 1) + (has_sv ? (a.sv_lane ? 2 : 4) : 0);   // store instructions per wave and tile
+  const int NS = 1 + (narr > 2 ? 2 : 1) + (has_sv ? (sv_lane ? 2 : 4) : 0);     // store instructions per wave and tile
   char* sStage = smem + G::STG_OFF;
   const __amdgpu_buffer_rsrc_t r_carry = pg_make_rsrc(carry);
   // vector memory operations of a wave complete in issue order and loads and stores share ONE counter, so a wait is
@@ -226,7 +234,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
     const float* carry_src = (t == 0 ? a.h0_32 : carry) + c * 64;
 
     auto stage = [&](int j, int buf) __attribute__((always_inline)) {
-      if (a.dbg & 1) return;
+      if (dbg & 1) return;
       char* tb = sT + buf * TILEB;
 #pragma unroll
       for (int i = 0; i < RP_WAVE; ++i) {
@@ -263,7 +271,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
     static_assert(ND == 9 || ND == 11, "wait_all_but has no case for this tile");
     stage(0, 0);
     if (ntile > 1) stage(1, 1);                        // block-uniform
-    if (a.dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (dbg & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else wait_all_but(ntile > 1 ? ND : 0);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -285,7 +293,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
       const int hi = lr >> 2;
       // LDS fragments are read in groups of 4 K-steps, two groups ahead of the MFMAs that consume them (the scheduling
       // barriers keep hipcc from sinking the reads back to their uses: one exposed LDS latency per MFMA otherwise)
-      if (!(a.dbg & 2)) {
+      if (!(dbg & 2)) {
         bf16x8 f[KS / 4][4];
 #pragma unroll
         for (int gk = 0; gk < 2; ++gk)
@@ -309,7 +317,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if constexpr (!L0) if (!(a.dbg & 2)) {
+      if constexpr (!L0) if (!(dbg & 2)) {
         const char* Wn = sWin + (wave * 16 + lr) * ROWW + ((lq ^ lr) & 3) * 16;   // chunk ks*4+lq of row lr sits at (ks*4+lq) ^ lr
         bf16x8 fx[KS / 4][4], fw[KS / 4][4];
 #pragma unroll
@@ -384,14 +392,14 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
       // tile j+1 must have landed (this wave's DMAs; the barrier extends it to the others): everything older than the
       // previous tile's stores.  The barrier also says that every wave is done reading tile j.
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (!(a.dbg & 1)) wait_all_but(j > 0 ? NS : 0);
+      if (!(dbg & 1)) wait_all_but(j > 0 ? NS : 0);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (j + 2 < ntile) stage(j + 2, buf);            // block-uniform
       asm volatile("" ::: "memory");
       {
         const unsigned oob = 0x80000000u;              // beyond the descriptors' 2^31 - 1 records: the store is dropped
-        const bool st = live && !((a.dbg & 4) && h[0] != 12345.678f);
+        const bool st = live && !((dbg & 4) && h[0] != 12345.678f);
         const long s = (long)(o + b) * H + u0;
         const unsigned o2 = st ? (unsigned)(s * 2) : oob;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{h[0], h[1], h[2], h[3]}), r_carry,
@@ -401,7 +409,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
         const char* SB = sStage + (j & 1) * G::STG_BUF;
         const int row = (lane >> 3) + ((wave & 1) << 3), seg = lane & 7;
         const int brow = g + NG * (16 * j + row);
-        const bool rlive = brow < Bt && !((a.dbg & 4) && h[0] != 12345.678f);
+        const bool rlive = brow < Bt && !((dbg & 4) && h[0] != 12345.678f);
         const unsigned orow = (unsigned)((((long)(o + brow) * H + c * 64) * 2) + seg * 16);
         for (int rd = 0; rd < (narr > 2 ? 2 : 1); ++rd) {   // kernel-uniform trip count
           const int arr = 2 * rd + (wave >> 1);                // wave-uniform
@@ -414,7 +422,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
         if (has_sv) {
           // r, z, n, hn go back to the BPTT kernel lane for lane: stored in lane order they are 512 contiguous bytes per
           // wave instruction (pg_persist.h, sv_tile_slot); packed rows when the BPTT of this step is not the persistent kernel
-          if (a.sv_lane) {   // kernel-uniform: (r, z) pairs in sv[l][0..1], (n, hn) pairs in sv[l][2..3], 16 bytes per lane
+          if (sv_lane) {   // kernel-uniform: (r, z) pairs in sv[l][0..1], (n, hn) pairs in sv[l][2..3], 16 bytes per lane
             const unsigned o16 = st ? (unsigned)(((sv_tile_slot(o, t, NG, j, g) * NCU + c) * 256 + wave * 64 + lane) * 16) : oob;
             const bf16x4 vr = to_bf16x4(r), vz = to_bf16x4(z), vn = to_bf16x4(n), vh = to_bf16x4(hn);
             const u32x2 ur = __builtin_bit_cast(u32x2, vr), uz = __builtin_bit_cast(u32x2, vz);
@@ -447,13 +455,14 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
   }
 }
 
-template <int H, int AUXL>
+template <int H, int AUXL, bool DBG, bool FAST>
 __global__ __launch_bounds__(256) void dec_fwd_persist_kernel(DecFwdPersist a, Sched sd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int g, l, c;   // blockIdx % 8 labels the XCD: a group's workgroups (or at least a layer's) share one
   if (!persist_map(blockIdx.x, a.NG, DecGeo<H>::NCU, g, l, c)) return;
-  if (l == 0) dec_fwd_body<H, true, AUXL>(a, sd, g, l, c, smem);
-  else dec_fwd_body<H, false, AUXL>(a, sd, g, l, c, smem);
+  if (l == 0) dec_fwd_body<H, 0, AUXL, DBG, FAST>(a, sd, g, l, c, smem);
+  else if (l == a.L - 1) dec_fwd_body<H, 2, AUXL, DBG, FAST>(a, sd, g, l, c, smem);
+  else dec_fwd_body<H, 1, AUXL, DBG, FAST>(a, sd, g, l, c, smem);
 }
 
 unsigned long long* g_stamps = nullptr;
@@ -518,13 +527,20 @@ int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t
   a.stamps = g_stamps_which == 0 ? g_stamps : nullptr;
   a.dbg = getenv("PG_PERSIST_DBG") ? atoi(getenv("PG_PERSIST_DBG")) : 0;
   PG_CHECK_HIP(hipMemsetAsync(a.sync, 0, PG_PERSIST_SYNC_WORDS * sizeof(unsigned), stream));
-  static bool attr_done = false;
-  if (!attr_done) {
-    PG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fwd_persist_kernel<512, AUX_SC1>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM));
-    PG_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_fwd_persist_kernel<512, 0>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM));
-    attr_done = true;
+  const bool dbgk = a.dbg != 0 || a.stamps != nullptr;
+  const bool plain = persist_dma_plain();
+  bool fast = !dbgk && !plain && a.L >= 2 && a.sv_lane && !getenv("PG_PERSIST_NO_FAST");      // the training configuration (see dec_fwd_body)
+  for (int l = 0; l < a.L; ++l) fast = fast && a.sv[l][0] && ((a.hdrop[l] != nullptr) == (l < a.L - 1));
+  const void* kern = fast    ? reinterpret_cast<const void*>(dec_fwd_persist_kernel<512, AUX_SC1, false, true>)
+                     : plain ? (dbgk ? reinterpret_cast<const void*>(dec_fwd_persist_kernel<512, 0, true, false>)
+                                     : reinterpret_cast<const void*>(dec_fwd_persist_kernel<512, 0, false, false>))
+                             : (dbgk ? reinterpret_cast<const void*>(dec_fwd_persist_kernel<512, AUX_SC1, true, false>)
+                                     : reinterpret_cast<const void*>(dec_fwd_persist_kernel<512, AUX_SC1, false, false>));
+  static bool attr_done[5] = {false, false, false, false, false};
+  const int ki = fast ? 4 : plain * 2 + dbgk;
+  if (!attr_done[ki]) {
+    PG_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM));
+    attr_done[ki] = true;
   }
   // Every workgroup waits for its peers, so the whole grid must be co-resident: one workgroup per CU (512 registers per
   // lane, 130 KB LDS) on a device with at least `grid` CUs.  Checked here; a plain launch has the same residency as a
@@ -537,10 +553,8 @@ int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t
     PG_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
   }
   PG_REQUIRE(grid <= n_cu, "dec_fwd_persist: %d workgroups cannot be co-resident on %d CUs", grid, n_cu);
-  if (persist_dma_plain())
-    hipLaunchKernelGGL((dec_fwd_persist_kernel<512, 0>), dim3(grid), dim3(256), (size_t)G::SMEM, stream, a, sd);
-  else
-    hipLaunchKernelGGL((dec_fwd_persist_kernel<512, AUX_SC1>), dim3(grid), dim3(256), (size_t)G::SMEM, stream, a, sd);
+  void* kargs[] = {&a, const_cast<Sched*>(&sd)};
+  PG_CHECK_HIP(hipLaunchKernel(kern, dim3(grid), dim3(256), kargs, (size_t)G::SMEM, stream));
   PG_CHECK_LAUNCH();
   PG_TRY(persist_fail_mirror(stream));
   return PG_OK;
