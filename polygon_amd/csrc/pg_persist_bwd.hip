@@ -64,6 +64,29 @@ __device__ __forceinline__ bool wait_ge(unsigned* p, unsigned target, unsigned* 
   }
 }
 
+// One part's share of a wave: four 1-KB rows by LDS-DMA, 16 bytes per lane from (base + 32-bit lane offset) to the LDS rows
+// m, m + 1024, ...  The instruction offset moves BOTH addresses, so the caller's lane offsets carry -i * 1024.  Issued from
+// asm with a scalar base, a row costs 3 instructions (live test, select, DMA) instead of the ~14 of a 64-bit address per row
+// - with one wave per SIMD every instruction is a quarter of an MFMA slot - and hipcc, which does not see the transfers,
+// adds no waits of its own for them.
+template <int AUXL>
+__device__ __forceinline__ void dma_rows4(unsigned v0, unsigned v1, unsigned v2, unsigned v3, const char* base, unsigned m) {
+  if constexpr (AUXL != 0)
+    asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %4 sc1\n\t"
+                 "global_load_lds_dwordx4 %1, %4 offset:1024 sc1\n\t"
+                 "global_load_lds_dwordx4 %2, %4 offset:2048 sc1\n\t"
+                 "global_load_lds_dwordx4 %3, %4 offset:3072 sc1" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(base), "s"(m)
+                 : "memory", "m0");
+  else
+    asm volatile("s_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %0, %4\n\t"
+                 "global_load_lds_dwordx4 %1, %4 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %2, %4 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %3, %4 offset:3072" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(base), "s"(m)
+                 : "memory", "m0");
+}
+
 // every wave issues 4 LDS-DMA instructions per part; `younger` = parts issued after the one that must have landed.
 // Counting fewer outstanding operations than there are (the epilogue's own loads and stores are not counted) only makes
 // the wait stricter: vector memory operations of one wave complete in issue order.
@@ -101,7 +124,13 @@ template <int H, bool TOP> struct BwdGeo {
   static constexpr int SMEM = WN_BYTES + NSLOT * PART_BYTES + STG_BYTES + 16;
 };
 
-template <int H, bool TOP, int AUXL, bool DBG>
+template <int V> struct IC { static constexpr int value = V; };
+
+// DBG: stamps and knock-out switches.  FAST: the training configuration (dropout between layers, saved activations in
+// lane order) known at compile time.  The step body is compiled three times - first step (no recurrent operand), steady
+// state, last step (t = -1, the gradient of h0) - so that the tile loop has no block-uniform branches left: one wave per
+// SIMD pays for every scalar branch with idle matrix pipes.
+template <int H, bool TOP, int AUXL, bool DBG, bool FAST>
 __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched& sd, int g, int l, int c, char* smem) {
   using G = BwdGeo<H, TOP>;
   const int dbg = DBG ? a.dbg : 0;
@@ -141,7 +170,8 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
     }
   }
   const float inv_keep = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
-  const bool drop = !TOP && a.p_drop > 0.0f;
+  const bool drop = FAST ? !TOP : (!TOP && a.p_drop > 0.0f);
+  const bool sv_lane = FAST ? true : a.sv_lane != 0;
   bf16_t* dGI = a.dGI[l];
   bf16_t* dGH = a.dGH[l];
   const bf16_t* dGIup = TOP ? nullptr : a.dGI[l + 1];
@@ -152,12 +182,22 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   f32x4 sdr = f32x4{0.f, 0.f, 0.f, 0.f}, sdz = sdr, sdnr = sdr, sdn = sdr;   // running sums for the bias gradients
+  // LDS-DMA lane offsets of this wave's rows wave*4 + i of a tile (bytes from the operand's column block - 3072): the
+  // XOR-swizzled chunk of the lane, + 3072 - i*1024 for dma_rows4's instruction offsets; `vdead` addresses sequence g
+  // (finished sequences re-read a valid row; their columns are masked), `vrow` the row's own sequence in the tile at hand
+  unsigned vdead[4], vrow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) vdead[i] = (unsigned)g * (3 * H * 2) + ((lane ^ (wave * 4 + i)) * 16) + 3072 - i * 1024;
+  const unsigned tile_step = 16u * NG * (3 * H * 2);
+  const unsigned lds_ring = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lptr_t)sR) + wave * 4096;
   __syncthreads();
 
-  for (int s = 0; s <= Tg; ++s) {
-    const int t = Tg - 1 - s;                      // t = -1: the gradient of h0
-    const bool has_own = s > 0;                    // step t+1 of this group exists
-    const bool has_up = !TOP && t >= 0;
+  auto step = [&](int s, auto PHc) __attribute__((always_inline)) -> bool {
+    constexpr int PH = decltype(PHc)::value;       // 0: first step, 1: steady state, 2: last step
+    const int t = Tg - 1 - s;                      // t = -1: the gradient of h0 (PH == 2)
+    constexpr bool has_own = PH != 0;              // step t+1 of this group exists
+    constexpr bool has_up = !TOP && PH != 2;
+    constexpr bool fin = PH == 2;
     PG_STAMP(0);
     // ---- wait for dGH_{l,t+1} (own layer) and dGI_{l+1,t} (layer above)
     if (tid == 0) {
@@ -173,15 +213,15 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
       *sFlag = ok ? 1u : 0u;
     }
     __syncthreads();
-    if (*sFlag == 0u) return;   // block-uniform: somebody gave up
+    if (*sFlag == 0u) return false;   // block-uniform: somebody gave up
     PG_STAMP(2);
-    const int tt = t >= 0 ? t : 0;
+    const int tt = fin ? 0 : t;
     const int o = sd.off[tt], Bt = sd.off[tt + 1] - o;             // rows of this step (t = -1: those of step 0)
-    const int o1 = t >= 0 ? sd.off[t + 1] : 0;                      // rows that carry a recurrent gradient: step t+1
-    const int Bt1 = !has_own ? 0 : (t >= 0 ? sd.off[t + 2] - o1 : Bt);
+    const int o1 = fin ? 0 : sd.off[t + 1];                         // rows that carry a recurrent gradient: step t+1
+    const int Bt1 = !has_own ? 0 : (fin ? Bt : sd.off[t + 2] - o1);
     const int nlive = (Bt - g + NG - 1) / NG;
     const int ntile = (nlive + 15) >> 4;
-    const int Pt = (has_own ? 3 : 0) + (has_up ? 3 : 0);           // parts per tile
+    constexpr int Pt = (has_own ? 3 : 0) + (has_up ? 3 : 0);       // parts per tile
     const int nparts = ntile * Pt;
     const bf16_t* own_base = dGH + (long)o1 * 3 * H;
     const bf16_t* up_base = TOP ? nullptr : dGIup + (long)o * 3 * H;
@@ -190,24 +230,27 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
 
     // flattened part sequence of the step: tile-major, own parts before upper parts
     int qi = 0, ji = 0, pi = 0, si = 0;            // next part to issue: index, tile, part in tile, slot
+    const char* own_b = reinterpret_cast<const char*>(own_base) - 3072;
+    const char* up_b = reinterpret_cast<const char*>(up_base) - 3072;
+    const int nl_own = Bt1 > g ? (Bt1 - g + NG - 1) / NG - wave * 4 : -wave * 4;   // live rows of the group, from this wave's first row
+    const int nl_up = nlive - wave * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vrow[i] = vdead[i] + (unsigned)(NG * (wave * 4 + i)) * (3 * H * 2);
     auto issue = [&]() __attribute__((always_inline)) {
-      if (qi < nparts && !(dbg & 1)) {           // block-uniform
+      if (qi < nparts && !(dbg & 1)) {             // block-uniform
         const bool own = has_own && pi < 3;
         const int sub = own ? pi : pi - (has_own ? 3 : 0);
-        const bf16_t* base = (own ? own_base : up_base) + sub * 512;
-        const int lim = own ? Bt1 : Bt;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = wave * 4 + i;
-          const int b = g + NG * (16 * ji + row);
-          const int bs = b < lim ? b : g;          // finished sequences re-read a valid row; their columns are masked
-          const bf16_t* src = base + (long)bs * 3 * H + ((lane ^ row) * 8);
-          char* dst = sR + si * PART_BYTES + row * 1024;
-          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, AUXL);
-        }
+        const int rem = (own ? nl_own : nl_up) - 16 * ji;   // row i of this wave is live when i < rem
+        dma_rows4<AUXL>(0 < rem ? vrow[0] : vdead[0], 1 < rem ? vrow[1] : vdead[1], 2 < rem ? vrow[2] : vdead[2],
+                        3 < rem ? vrow[3] : vdead[3], (own ? own_b : up_b) + sub * 1024, lds_ring + si * PART_BYTES);
       }
       ++qi;
-      if (++pi == Pt) { pi = 0; ++ji; }
+      if (++pi == Pt) {
+        pi = 0;
+        ++ji;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vrow[i] += tile_step;
+      }
       if (++si == NSLOT) si = 0;
     };
     if (nparts > 0) {
@@ -243,11 +286,11 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
       f32x4 cr = f32x4{0.f, 0.f, 0.f, 0.f}, dtop = f32x4{0.f, 0.f, 0.f, 0.f};
       bf16x4 svr, svz, svn, svhn, svhp;
       if (has_own && !(dbg & 4)) cr = *reinterpret_cast<const f32x4*>(carry + (long)bs * H + u0);
-      if (t >= 0 && !(dbg & 4)) {
+      if (!fin && !(dbg & 4)) {
         const long sidx = (long)(o + bs) * H + u0;
         if constexpr (TOP) dtop = *reinterpret_cast<const f32x4*>(a.dout + sidx);
         // lane order, as the forward kernel wrote them (pg_persist.h, sv_tile_slot)
-        if (a.sv_lane) {   // kernel-uniform: (r, z) and (n, hn) pairs, 16 bytes per lane each (pg_persist_dec.hip)
+        if (sv_lane) {   // kernel-uniform: (r, z) and (n, hn) pairs, 16 bytes per lane each (pg_persist_dec.hip)
           const long sl = ((sv_tile_slot(o, t, NG, j, g) * NCU + c) * 256 + wave * 64 + lane) * 8;
           const u32x4 prz = *reinterpret_cast<const u32x4*>(a.sv[l][0] + sl);
           const u32x4 pnh = *reinterpret_cast<const u32x4*>(a.sv[l][2] + sl);
@@ -266,7 +309,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
       f32x4 ah[2], au[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) { ah[i] = f32x4{0.f, 0.f, 0.f, 0.f}; au[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      if (has_own) {   // block-uniform
+      if constexpr (has_own) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
           const char* A = part_begin();
@@ -293,7 +336,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
         }
       }
       if constexpr (!TOP) {
-        if (has_up) {
+        if constexpr (has_up) {
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
             const char* A = part_begin();
@@ -365,7 +408,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
       // ---- epilogue on 4 units of sequence b
       float dh[4];
       float m[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-      if (drop && t >= 0) dropout_scale4(a.seed, l, t, b * a.b_mul + a.b_add, u0 >> 2, a.p_drop, inv_keep, m);
+      if (drop && !fin) dropout_scale4(a.seed, l, t, b * a.b_mul + a.b_add, u0 >> 2, a.p_drop, inv_keep, m);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float d = live1 ? cr[e] + ah[0][e] + ah[1][e] : 0.0f;
@@ -373,7 +416,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
         else d += m[e] * (au[0][e] + au[1][e]);
         dh[e] = d;
       }
-      if (t < 0) {
+      if constexpr (fin) {
         if (live) *reinterpret_cast<f32x4*>(a.dh0[l] + (long)b * H + u0) = f32x4{dh[0], dh[1], dh[2], dh[3]};
         continue;
       }
@@ -426,7 +469,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     PG_STAMP(6);
-    if (tid == 0 && t >= 0) {
+    if (tid == 0 && !fin) {
       if constexpr (AUXL == 0) {   // plain payload stores: lane-0 agent release (L2 write-back) before the arrival
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -434,7 +477,12 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
       __hip_atomic_fetch_add(cnt_own, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     PG_STAMP(7);
-  }
+    return true;
+  };
+  if (!step(0, IC<0>{})) return;
+  for (int s = 1; s < Tg; ++s)
+    if (!step(s, IC<1>{})) return;
+  if (!step(Tg, IC<2>{})) return;
   // ---- bias gradients: the 16 lanes that share this lane's units (one per sequence row of the tile) are summed, then one
   // lane adds 4 units x 3 gates per array
   if (a.dbhh[l] || a.dbih[l]) {
@@ -459,15 +507,15 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
   }
 }
 
-template <int H, int AUXL, bool DBG>
+template <int H, int AUXL, bool DBG, bool FAST>
 __global__ __launch_bounds__(256) void dec_bwd_persist_kernel(DecBwdPersist a, Sched sd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NCU = H / 64;
   int g, li, c;   // blockIdx % 8 labels the XCD: a group's workgroups (or at least a layer's) share one
   if (!persist_map(blockIdx.x, a.NG, NCU, g, li, c)) return;
   const int l = a.L - 1 - li;                               // top layer first: it is the head of the dependency chain
-  if (l == a.L - 1) dec_bwd_body<H, true, AUXL, DBG>(a, sd, g, l, c, smem);
-  else dec_bwd_body<H, false, AUXL, DBG>(a, sd, g, l, c, smem);
+  if (l == a.L - 1) dec_bwd_body<H, true, AUXL, DBG, FAST>(a, sd, g, l, c, smem);
+  else dec_bwd_body<H, false, AUXL, DBG, FAST>(a, sd, g, l, c, smem);
 }
 
 // dh0 = sum over layers of the per-layer h0 gradients (every layer starts from the same decoder_lat(z))
@@ -503,14 +551,17 @@ int launch_dec_bwd_persist(DecBwdPersist& a, const Sched& sd, int H, float* dh0_
   PG_CHECK_HIP(hipMemsetAsync(a.sync, 0, PG_PERSIST_SYNC_WORDS * sizeof(unsigned), stream));
   const bool dbgk = a.dbg != 0 || a.stamps != nullptr;
   const bool plain = persist_dma_plain();
-  const void* kern = plain ? (dbgk ? reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, 0, true>)
-                                   : reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, 0, false>))
-                           : (dbgk ? reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, AUX_SC1, true>)
-                                   : reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, AUX_SC1, false>));
-  static bool attr_done[4] = {false, false, false, false};
-  if (!attr_done[plain * 2 + dbgk]) {
+  const bool fast = !dbgk && !plain && a.L >= 2 && a.sv_lane && a.p_drop > 0.0f && !getenv("PG_PERSIST_NO_FAST");
+  const void* kern = fast    ? reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, AUX_SC1, false, true>)
+                     : plain ? (dbgk ? reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, 0, true, false>)
+                                     : reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, 0, false, false>))
+                             : (dbgk ? reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, AUX_SC1, true, false>)
+                                     : reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, AUX_SC1, false, false>));
+  static bool attr_done[5] = {false, false, false, false, false};
+  const int ki = fast ? 4 : plain * 2 + dbgk;
+  if (!attr_done[ki]) {
     PG_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    attr_done[plain * 2 + dbgk] = true;
+    attr_done[ki] = true;
   }
   const int grid = a.NG == 8 ? 8 * a.L * GL::NCU : 256;   // co-residency: one workgroup per CU (checked against the CU count by the forward launcher's rule)
   static int n_cu = 0;
