@@ -39,6 +39,12 @@ __device__ __forceinline__ f32x4 mma16a(const bf16x8& w, const bf16x8& x, f32x4 
   asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "a"(w), "v"(x));
   return c;
 }
+// the same without the nop: for an MFMA whose accumulator was last written by an MFMA (every one but a tile's first per
+// accumulator) - the 96 nops of a tile were 6 % of its instructions, and one wave per SIMD issues one instruction at a time
+__device__ __forceinline__ f32x4 mma16a_nn(const bf16x8& w, const bf16x8& x, f32x4 c) {
+  asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "a"(w), "v"(x));
+  return c;
+}
 // matrix-pipe write -> VALU read wait states; tied to the accumulators so that every MFMA asm is ordered before it
 #define PG_MFMA_DRAIN(a0, a1, a2, a3) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3))
 __device__ __forceinline__ bf16x4 to_bf16x4(const float (&v)[4]) {
@@ -228,53 +234,70 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
     const __amdgpu_buffer_rsrc_t r_dGI = pg_make_rsrc(dGI + (long)o * 3 * H);
     const __amdgpu_buffer_rsrc_t r_dGH = pg_make_rsrc(dGH + (long)o * 3 * H);
 
-    // flattened part sequence of the step: tile-major, own parts before upper parts
-    int qi = 0, ji = 0, pi = 0, si = 0;            // next part to issue: index, tile, part in tile, slot
+    // The step's parts, tile-major, own parts before upper parts; the ring runs AHEAD = D + 1 parts in front of the consumer.
+    // A tile's parts are unrolled, so WHICH part is issued behind part p (p + AHEAD: its operand, column block and tile
+    // offset) is known at compile time; only the ring slots, the tile of the issue stream and the live-row count are run-time.
+    constexpr int AHEAD = D + 1;
+    constexpr int RING = NSLOT * PART_BYTES;
     const char* own_b = reinterpret_cast<const char*>(own_base) - 3072;
     const char* up_b = reinterpret_cast<const char*>(up_base) - 3072;
     const int nl_own = Bt1 > g ? (Bt1 - g + NG - 1) / NG - wave * 4 : -wave * 4;   // live rows of the group, from this wave's first row
     const int nl_up = nlive - wave * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) vrow[i] = vdead[i] + (unsigned)(NG * (wave * 4 + i)) * (3 * H * 2);
-    auto issue = [&]() __attribute__((always_inline)) {
-      if (qi < nparts && !(dbg & 1)) {             // block-uniform
-        const bool own = has_own && pi < 3;
-        const int sub = own ? pi : pi - (has_own ? 3 : 0);
-        const int rem = (own ? nl_own : nl_up) - 16 * ji;   // row i of this wave is live when i < rem
+    int si = 0, sc = 0;                            // ring offsets (bytes) of the next part to issue / to consume
+    int jrow = 0;                                  // 16 x the tile of the issue stream (vrow addresses that tile's rows)
+    auto issue_part = [&](auto PPc) __attribute__((always_inline)) {
+      constexpr int pp = decltype(PPc)::value;     // part of the issue stream's tile
+      constexpr bool own = has_own && pp < 3;
+      constexpr int sub = own ? pp : pp - (has_own ? 3 : 0);
+      if (!(dbg & 1)) {
+        const int rem = (own ? nl_own : nl_up) - jrow;   // row i of this wave is live when i < rem
         dma_rows4<AUXL>(0 < rem ? vrow[0] : vdead[0], 1 < rem ? vrow[1] : vdead[1], 2 < rem ? vrow[2] : vdead[2],
-                        3 < rem ? vrow[3] : vdead[3], (own ? own_b : up_b) + sub * 1024, lds_ring + si * PART_BYTES);
+                        3 < rem ? vrow[3] : vdead[3], (own ? own_b : up_b) + sub * 1024, lds_ring + si);
       }
-      ++qi;
-      if (++pi == Pt) {
-        pi = 0;
-        ++ji;
+      si += PART_BYTES;
+      if (si == RING) si = 0;
+      if constexpr (pp == Pt - 1) {
+        jrow += 16;
 #pragma unroll
         for (int i = 0; i < 4; ++i) vrow[i] += tile_step;
       }
-      if (++si == NSLOT) si = 0;
     };
-    if (nparts > 0) {
-#pragma unroll 1
-      for (int i = 0; i <= D; ++i) issue();
-    }
+    auto prologue = [&](auto Kc, auto&& self) __attribute__((always_inline)) -> void {
+      constexpr int k = decltype(Kc)::value;
+      if constexpr (Pt > 0 && k < AHEAD) {
+        if (k / Pt < ntile) {                      // block-uniform
+          issue_part(IC<k % (Pt > 0 ? Pt : 1)>{});
+          self(IC<k + 1>{}, self);
+        }
+      }
+    };
+    prologue(IC<0>{}, prologue);
     PG_STAMP(3);
-    int qc = 0, sc = 0;                            // part being consumed, its slot
     // one part: wait for its DMAs, publish them, refill the slot freed by the previous part, 16 K-steps
-    auto part_begin = [&]() __attribute__((always_inline)) -> const char* {
-      const int younger = nparts - 1 - qc;
+    auto part_begin = [&](int j, auto Pc) __attribute__((always_inline)) -> const char* {
+      constexpr int pt = decltype(Pc)::value;      // part of tile j
+      constexpr int c = Pt - 1 - pt;               // parts of this tile behind it
       if (!(dbg & 1)) {
-        if (younger >= D) wait_parts(D);       // steady state: one compare, the immediate is a constant
-        else wait_parts(younger);
+        if constexpr (c >= D) {
+          wait_parts(D);
+        } else {
+          const int younger = (ntile - 1 - j) * Pt + c;
+          if (younger >= D) wait_parts(D);
+          else wait_parts(younger);
+        }
       }
       // a bare s_barrier: __syncthreads() carries a workgroup release fence = vmcnt(0), which would drain the very DMAs
       // this pipeline keeps in flight.  Nothing but the DMA'd slot is communicated here (the wave's own LDS reads of the
       // previous part were consumed by its MFMAs), so the counted wait above is the only ordering needed.
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      issue();
-      const char* A = sR + sc * PART_BYTES + lr * 1024 + ((lq ^ lr) & 3) * 16;
-      ++qc;
-      if (++sc == NSLOT) sc = 0;
+      constexpr int k = pt + AHEAD, dj = k / (Pt > 0 ? Pt : 1), pp = k % (Pt > 0 ? Pt : 1);
+      if (dj == 0 || j + dj < ntile) issue_part(IC<pp>{});   // block-uniform
+      const char* A = sR + sc + lr * 1024 + ((lq ^ lr) & 3) * 16;
+      sc += PART_BYTES;
+      if (sc == RING) sc = 0;
       return A;
     };
 
@@ -310,10 +333,10 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
 #pragma unroll
       for (int i = 0; i < 2; ++i) { ah[i] = f32x4{0.f, 0.f, 0.f, 0.f}; au[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       if constexpr (has_own) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          const char* A = part_begin();
-          if (dbg & 2) continue;
+        auto own_part = [&](auto Pc) __attribute__((always_inline)) {
+          constexpr int p = decltype(Pc)::value;
+          const char* A = part_begin(j, Pc);
+          if (dbg & 2) return;
           // the part's 16 activation fragments are read in groups of 4, two groups (8 reads, <= 0.5 us of MFMAs) ahead of
           // the MFMAs that consume them; the scheduling barriers keep hipcc from sinking the reads back to their uses
           bf16x8 f[4][4];
@@ -330,19 +353,24 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ah[i & 1] = mma16a(wh[p * 16 + gk * 4 + i], f[gk][i], ah[i & 1]);
+            for (int i = 0; i < 4; ++i) {
+              if (p == 0 && gk == 0) ah[i & 1] = mma16a(wh[p * 16 + gk * 4 + i], f[gk][i], ah[i & 1]);
+              else ah[i & 1] = mma16a_nn(wh[p * 16 + gk * 4 + i], f[gk][i], ah[i & 1]);
+            }
             __builtin_amdgcn_sched_barrier(0);
           }
-        }
+        };
+        own_part(IC<0>{});
+        own_part(IC<1>{});
+        own_part(IC<2>{});
       }
       if constexpr (!TOP) {
         if constexpr (has_up) {
-#pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            const char* A = part_begin();
-            if (dbg & 2) continue;
-            // the part's 16 activation fragments are read in groups of 4, two groups (8 reads, <= 0.5 us of MFMAs) ahead of
-            // the MFMAs that consume them; the scheduling barriers keep hipcc from sinking the reads back to their uses
+          constexpr int P0 = has_own ? 3 : 0;      // the upper parts follow the own parts of the tile
+          auto up_part = [&](auto Pc) __attribute__((always_inline)) {
+            constexpr int p = decltype(Pc)::value;
+            const char* A = part_begin(j, IC<P0 + p>{});
+            if (dbg & 2) return;
             bf16x8 f[4][4];
 #pragma unroll
             for (int gk = 0; gk < 2; ++gk)
@@ -358,14 +386,17 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
               __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                if (p == 0) au[i & 1] = mma16a(wu[p * 16 + gk * 4 + i], f[gk][i], au[i & 1]);
+                if (p == 0 && gk == 0) au[i & 1] = mma16a(wu[p * 16 + gk * 4 + i], f[gk][i], au[i & 1]);
+                else if (p == 0) au[i & 1] = mma16a_nn(wu[p * 16 + gk * 4 + i], f[gk][i], au[i & 1]);
                 else au[i & 1] = mma16(wu[p * 16 + gk * 4 + i], f[gk][i], au[i & 1]);
               }
               __builtin_amdgcn_sched_barrier(0);
             }
-          }
+          };
+          up_part(IC<0>{});
+          up_part(IC<1>{});
           {
-            const char* A = part_begin();
+            const char* A = part_begin(j, IC<P0 + 2>{});
             const char* Wn = sWn + (wave * 16 + lr) * ROWW + ((lq ^ lr) & 3) * 16;   // chunk ks*4+lq of row lr sits at (ks*4+lq) ^ lr
             if (!(dbg & 2)) {
             // activation and weight fragments both come from LDS here: groups of 4 K-steps, one group ahead
