@@ -45,6 +45,31 @@ __device__ __forceinline__ f32x4 mma16a_nn(const bf16x8& w, const bf16x8& x, f32
   asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "a"(w), "v"(x));
   return c;
 }
+// A group of four K-steps as ONE asm statement: hipcc then waits once for the group's four LDS fragments (left alone it puts
+// an exact lgkmcnt wait in front of every single-MFMA asm, and a nop between asm statements that share an accumulator) -
+// ~100 fewer instructions per tile.  Accumulation on the same destination two MFMAs apart is interlocked by the hardware.
+// FIRST: the tile's first group, whose accumulators were just zeroed by VALU moves (2 wait states).  WA: the weight fragments
+// live in AGPRs ("a") or in VGPRs / come from LDS ("v").
+#define PG_MMA4_BODY                                 \
+  "v_mfma_f32_16x16x32_bf16 %0, %2, %6, %0\n\t"      \
+  "v_mfma_f32_16x16x32_bf16 %1, %3, %7, %1\n\t"      \
+  "v_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n\t"      \
+  "v_mfma_f32_16x16x32_bf16 %1, %5, %9, %1"
+template <bool FIRST, bool WA>
+__device__ __forceinline__ void mma16_x4(f32x4& c0, f32x4& c1, const bf16x8& w0, const bf16x8& w1, const bf16x8& w2,
+                                         const bf16x8& w3, const bf16x8& x0, const bf16x8& x1, const bf16x8& x2, const bf16x8& x3) {
+  if constexpr (WA) {
+    if constexpr (FIRST)
+      asm("s_nop 1\n\t" PG_MMA4_BODY : "+v"(c0), "+v"(c1) : "a"(w0), "a"(w1), "a"(w2), "a"(w3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+    else
+      asm(PG_MMA4_BODY : "+v"(c0), "+v"(c1) : "a"(w0), "a"(w1), "a"(w2), "a"(w3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+  } else {
+    if constexpr (FIRST)
+      asm("s_nop 1\n\t" PG_MMA4_BODY : "+v"(c0), "+v"(c1) : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+    else
+      asm(PG_MMA4_BODY : "+v"(c0), "+v"(c1) : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+  }
+}
 // matrix-pipe write -> VALU read wait states; tied to the accumulators so that every MFMA asm is ordered before it
 #define PG_MFMA_DRAIN(a0, a1, a2, a3) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3))
 __device__ __forceinline__ bf16x4 to_bf16x4(const float (&v)[4]) {
@@ -352,11 +377,9 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
               for (int i = 0; i < 4; ++i) f[gk + 2][i] = *reinterpret_cast<const bf16x8*>(A + ((((gk + 2) * 4 + i) ^ hi) << 6));
             }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              if (p == 0 && gk == 0) ah[i & 1] = mma16a(wh[p * 16 + gk * 4 + i], f[gk][i], ah[i & 1]);
-              else ah[i & 1] = mma16a_nn(wh[p * 16 + gk * 4 + i], f[gk][i], ah[i & 1]);
-            }
+            const int k0 = p * 16 + gk * 4;
+            if (p == 0 && gk == 0) mma16_x4<true, true>(ah[0], ah[1], wh[k0], wh[k0 + 1], wh[k0 + 2], wh[k0 + 3], f[gk][0], f[gk][1], f[gk][2], f[gk][3]);
+            else mma16_x4<false, true>(ah[0], ah[1], wh[k0], wh[k0 + 1], wh[k0 + 2], wh[k0 + 3], f[gk][0], f[gk][1], f[gk][2], f[gk][3]);
             __builtin_amdgcn_sched_barrier(0);
           }
         };
@@ -384,12 +407,10 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
                 for (int i = 0; i < 4; ++i) f[gk + 2][i] = *reinterpret_cast<const bf16x8*>(A + ((((gk + 2) * 4 + i) ^ hi) << 6));
               }
               __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                if (p == 0 && gk == 0) au[i & 1] = mma16a(wu[p * 16 + gk * 4 + i], f[gk][i], au[i & 1]);
-                else if (p == 0) au[i & 1] = mma16a_nn(wu[p * 16 + gk * 4 + i], f[gk][i], au[i & 1]);
-                else au[i & 1] = mma16(wu[p * 16 + gk * 4 + i], f[gk][i], au[i & 1]);
-              }
+              const int k0 = p * 16 + gk * 4;
+              if (p == 0 && gk == 0) mma16_x4<true, true>(au[0], au[1], wu[k0], wu[k0 + 1], wu[k0 + 2], wu[k0 + 3], f[gk][0], f[gk][1], f[gk][2], f[gk][3]);
+              else if (p == 0) mma16_x4<false, true>(au[0], au[1], wu[k0], wu[k0 + 1], wu[k0 + 2], wu[k0 + 3], f[gk][0], f[gk][1], f[gk][2], f[gk][3]);
+              else mma16_x4<false, false>(au[0], au[1], wu[k0], wu[k0 + 1], wu[k0 + 2], wu[k0 + 3], f[gk][0], f[gk][1], f[gk][2], f[gk][3]);
               __builtin_amdgcn_sched_barrier(0);
             }
           };
@@ -423,11 +444,8 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
                 }
               }
               __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                if (gk & 1) au[i & 1] = mma16(wb[i], xb[i], au[i & 1]);
-                else au[i & 1] = mma16(wa[i], xa[i], au[i & 1]);
-              }
+              if (gk & 1) mma16_x4<false, false>(au[0], au[1], wb[0], wb[1], wb[2], wb[3], xb[0], xb[1], xb[2], xb[3]);
+              else mma16_x4<false, false>(au[0], au[1], wa[0], wa[1], wa[2], wa[3], xa[0], xa[1], xa[2], xa[3]);
               __builtin_amdgcn_sched_barrier(0);
             }
             }
