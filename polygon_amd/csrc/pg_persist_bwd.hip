@@ -118,6 +118,32 @@ __device__ __forceinline__ void dma_rows4(unsigned v0, unsigned v1, unsigned v2,
                  : "memory", "m0");
 }
 
+// Epilogue inputs loaded from asm (32-bit lane offset, scalar base): hipcc, which does not see the LDS-DMA transfers, would
+// guard a load of its own with vmcnt(0) at the first use and drain the ring once per tile; loaded here and waited for with
+// the exact count (epi_wait) the ring stays in flight.  The destination registers must not be touched before epi_wait:
+// tools/check_mfma_hazard.py checks the listing for that.
+__device__ __forceinline__ void epi_ld16(u32x4& d, unsigned voff, const void* base) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 ; PG_EPI_LOAD" : "=v"(d) : "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void epi_ld8(u32x2& d, unsigned voff, const void* base) {
+  asm volatile("global_load_dwordx2 %0, %1, %2 ; PG_EPI_LOAD" : "=v"(d) : "v"(voff), "s"(base) : "memory");
+}
+// all = every one of the tile's NP parts was issued behind the loads (4 LDS-DMA instructions each): they may stay in
+// flight; else the step is ending and everything is waited for
+template <int NP>
+__device__ __forceinline__ void epi_wait(bool all, u32x4& a0, u32x4& a1, u32x4& a2, u32x4& a3, u32x2& a4) {
+  static_assert(NP == 6 || NP == 3, "parts per tile");
+  // the waits carry no register operands (hipcc would set up such operands with copies IN FRONT of the wait); the loaded
+  // registers are handed to the compiler by the empty asm behind the join
+  if (all) {
+    if constexpr (NP == 6) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  asm volatile("; PG_EPI_WAIT" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4)::"memory");
+}
+
 // every wave issues 4 LDS-DMA instructions per part; `younger` = parts issued after the one that must have landed.
 // Counting fewer outstanding operations than there are (the epilogue's own loads and stores are not counted) only makes
 // the wait stricter: vector memory operations of one wave complete in issue order.
@@ -149,7 +175,7 @@ template <int H, bool TOP> struct BwdGeo {
   static constexpr int NCU = H / 64;
   static constexpr int ROWW = H * 2;             // LDS row of the n-gate columns of W_ih_up^T: unpadded, chunk q of row u at q ^ (u & 15)
   static constexpr int WN_BYTES = TOP ? 0 : 64 * ROWW;
-  static constexpr int NSLOT = TOP ? 8 : 5;
+  static constexpr int NSLOT = TOP ? 8 : 4;     // measured: 3 slots 1402 us, 4 slots 1292, 5 slots 1346 (the epilogue drains what is in flight)
   static constexpr int D = NSLOT - 2;            // parts in flight behind the one being consumed
   static constexpr int STG_BYTES = 4 * 16 * 128;  // staging of a tile's gate gradients: dr, dz, dn.r, dn x 16 rows x 64 units (bf16)
   static constexpr int SMEM = WN_BYTES + NSLOT * PART_BYTES + STG_BYTES + 16;
@@ -333,6 +359,18 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
       // epilogue inputs of this lane's sequence, fetched under the tile's MFMAs
       f32x4 cr = f32x4{0.f, 0.f, 0.f, 0.f}, dtop = f32x4{0.f, 0.f, 0.f, 0.f};
       bf16x4 svr, svz, svn, svhn, svhp;
+      constexpr bool ASMLD = FAST && !fin && Pt > 0;   // (FAST: lane-order saves, no knock-out switches)
+      u32x4 q_cr = u32x4{0u, 0u, 0u, 0u}, q_top = q_cr, q_rz = q_cr, q_nh = q_cr;
+      u32x2 q_hp = u32x2{0u, 0u};
+      if constexpr (ASMLD) {
+        const unsigned sidx = (unsigned)((o + bs) * H + u0);     // < 2^31 / 4: N * H elements
+        if constexpr (has_own) epi_ld16(q_cr, (unsigned)(bs * H + u0) * 4u, carry);
+        if constexpr (TOP) epi_ld16(q_top, sidx * 4u, a.dout);
+        const unsigned sl = (unsigned)(((sv_tile_slot(o, t, NG, j, g) * NCU + c) * 256 + wave * 64 + lane) * 16);
+        epi_ld16(q_rz, sl, a.sv[l][0]);
+        epi_ld16(q_nh, sl, a.sv[l][2]);
+        epi_ld8(q_hp, sidx * 2u, a.sv[l][4]);
+      } else {
       if (has_own && !(dbg & 4)) cr = *reinterpret_cast<const f32x4*>(carry + (long)bs * H + u0);
       if (!fin && !(dbg & 4)) {
         const long sidx = (long)(o + bs) * H + u0;
@@ -353,6 +391,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
           svhn = *reinterpret_cast<const bf16x4*>(a.sv[l][3] + sidx);
         }
         svhp = *reinterpret_cast<const bf16x4*>(a.sv[l][4] + sidx);
+      }
       }
       f32x4 ah[2], au[2];
 #pragma unroll
@@ -454,6 +493,16 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
       }
       PG_MFMA_DRAIN(ah[0], ah[1], au[0], au[1]);
       if (j == 0) PG_STAMP(4);
+      if constexpr (ASMLD) {
+        epi_wait<Pt>(j * Pt + Pt + AHEAD <= nparts, q_cr, q_top, q_rz, q_nh, q_hp);
+        cr = __builtin_bit_cast(f32x4, q_cr);
+        dtop = __builtin_bit_cast(f32x4, q_top);
+        svr = __builtin_bit_cast(bf16x4, u32x2{q_rz[0], q_rz[1]});
+        svz = __builtin_bit_cast(bf16x4, u32x2{q_rz[2], q_rz[3]});
+        svn = __builtin_bit_cast(bf16x4, u32x2{q_nh[0], q_nh[1]});
+        svhn = __builtin_bit_cast(bf16x4, u32x2{q_nh[2], q_nh[3]});
+        svhp = __builtin_bit_cast(bf16x4, q_hp);
+      }
       // ---- epilogue on 4 units of sequence b
       float dh[4];
       float m[4] = {1.0f, 1.0f, 1.0f, 1.0f};

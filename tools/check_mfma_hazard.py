@@ -15,6 +15,9 @@ def main(path):
     ins = []
     for line in open(path):
         t = line.strip()
+        if "PG_EPI_WAIT" in t:
+            ins.append("; PG_EPI_WAIT")
+            continue
         if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
             continue
         ins.append(t)
@@ -28,6 +31,8 @@ def main(path):
         states = 0
         for k in range(i - 1, max(i - 6, -1), -1):
             p = ins[k]
+            if p.startswith(";"):
+                continue
             if p.startswith("s_nop"):
                 states += int(p.split()[1]) + 1
                 continue
@@ -40,7 +45,28 @@ def main(path):
                     bad += 1
             states += 1
     print("%s: %d MFMA hazards" % (path, bad))
-    return 1 if bad else 0
+    # asm-issued epilogue loads (PG_EPI_LOAD) must not have their destination registers touched before PG_EPI_WAIT
+    pending, touched, nload = set(), 0, 0
+    for t in ins:
+        if t.startswith("s_endpgm"):
+            pending = set()
+        if "PG_EPI_LOAD" in t:
+            pending |= regs(t.split(None, 1)[1].split(",")[0].strip())
+            nload += 1
+            continue
+        if "PG_EPI_WAIT" in t:
+            pending = set()
+            continue
+        if pending and not t.startswith(("s_", ";")):
+            body = t.split(";")[0]
+            used = set()
+            for tok in re.findall(r"[av]\[\d+:\d+\]|\b[av]\d+\b", body):
+                used |= regs(tok)
+            if used & pending:
+                print("epilogue load register touched before its wait: %s" % t)
+                touched += 1
+    print("%s: %d epilogue loads, %d early touches" % (path, nload, touched))
+    return 1 if bad or touched else 0
 
 if __name__ == "__main__":
     sys.exit(main(sys.argv[1]))
