@@ -46,40 +46,6 @@ __device__ __forceinline__ f32x4 mma16a(const bf16x8& w, const bf16x8& x, f32x4 
   asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "a"(w), "v"(x));
   return c;
 }
-// Four K-steps x three gates as ONE asm statement (12 MFMAs; accumulators %0-%2, weights %3-%14 gate-major, activation
-// fragments %15-%18): hipcc then waits once for the group's LDS fragments instead of once per single-MFMA asm, and the
-// per-MFMA nop goes (one wave per SIMD issues one instruction at a time: the 96 nops of a tile were an eighth of its
-// instructions).  Accumulation on one destination three MFMAs apart is interlocked by the hardware.  FIRST: the tile's
-// first group, behind the VALU moves that zero the accumulators.  CA/CB/CC: register class of each gate's weights.
-#define PG_MMA12_BODY                                 \
-  "v_mfma_f32_16x16x32_bf16 %0, %3, %15, %0\n\t"      \
-  "v_mfma_f32_16x16x32_bf16 %1, %7, %15, %1\n\t"      \
-  "v_mfma_f32_16x16x32_bf16 %2, %11, %15, %2\n\t"     \
-  "v_mfma_f32_16x16x32_bf16 %0, %4, %16, %0\n\t"      \
-  "v_mfma_f32_16x16x32_bf16 %1, %8, %16, %1\n\t"      \
-  "v_mfma_f32_16x16x32_bf16 %2, %12, %16, %2\n\t"     \
-  "v_mfma_f32_16x16x32_bf16 %0, %5, %17, %0\n\t"      \
-  "v_mfma_f32_16x16x32_bf16 %1, %9, %17, %1\n\t"      \
-  "v_mfma_f32_16x16x32_bf16 %2, %13, %17, %2\n\t"     \
-  "v_mfma_f32_16x16x32_bf16 %0, %6, %18, %0\n\t"      \
-  "v_mfma_f32_16x16x32_bf16 %1, %10, %18, %1\n\t"     \
-  "v_mfma_f32_16x16x32_bf16 %2, %14, %18, %2"
-#define PG_MMA12_OPS(CA, CB, CC)                                                                                         \
-  : "+v"(c0), "+v"(c1), "+v"(c2)                                                                                         \
-  : CA(wa[0]), CA(wa[1]), CA(wa[2]), CA(wa[3]), CB(wb[0]), CB(wb[1]), CB(wb[2]), CB(wb[3]), CC(wc[0]), CC(wc[1]), CC(wc[2]), \
-    CC(wc[3]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3])
-// all three gates' weights in AGPRs (the recurrent half)
-template <bool FIRST>
-__device__ __forceinline__ void mma12_aaa(f32x4& c0, f32x4& c1, f32x4& c2, const bf16x8* wa, const bf16x8* wb, const bf16x8* wc,
-                                          const bf16x8* x) {
-  if constexpr (FIRST) asm("s_nop 1\n\t" PG_MMA12_BODY PG_MMA12_OPS("a", "a", "a"));
-  else asm(PG_MMA12_BODY PG_MMA12_OPS("a", "a", "a"));
-}
-// input half: r weights in AGPRs, z weights in VGPRs, n weights read from LDS
-__device__ __forceinline__ void mma12_avv(f32x4& c0, f32x4& c1, f32x4& c2, const bf16x8* wa, const bf16x8* wb, const bf16x8* wc,
-                                          const bf16x8* x) {
-  asm(PG_MMA12_BODY PG_MMA12_OPS("a", "v", "v"));
-}
 // tied to the accumulators: every MFMA that produces them is ordered before it and every consumer after it (a bare
 // asm volatile would not order the non-volatile MFMA asms)
 #define PG_MFMA_DRAIN(a0, a1, a2, a3) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3))

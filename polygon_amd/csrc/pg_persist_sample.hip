@@ -291,13 +291,8 @@ __device__ __forceinline__ void layer_body(const DecSamplePersist& a, int g, int
               for (int i = 0; i < 4; ++i) f[gk + 2][i] = *reinterpret_cast<const bf16x8*>(A + ((((gk + 2) * 4 + i) ^ hi) << 6));
             }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int ks = gk * 4 + i;
-              acc[0] = mma16a(wh[0][ks], f[gk][i], acc[0]);
-              acc[1] = mma16a(wh[1][ks], f[gk][i], acc[1]);
-              acc[2] = mma16a(wh[2][ks], f[gk][i], acc[2]);
-            }
+            if (gk == 0) mma12_aaa<true>(acc[0], acc[1], acc[2], &wh[0][gk * 4], &wh[1][gk * 4], &wh[2][gk * 4], f[gk]);
+            else mma12_aaa<false>(acc[0], acc[1], acc[2], &wh[0][gk * 4], &wh[1][gk * 4], &wh[2][gk * 4], f[gk]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -321,13 +316,7 @@ __device__ __forceinline__ void layer_body(const DecSamplePersist& a, int g, int
               }
             }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int ks = gk * 4 + i;
-              acc[0] = mma16a(wi[0][ks], fx[gk][i], acc[0]);
-              acc[1] = mma16(wi[1][ks], fx[gk][i], acc[1]);
-              acc[3] = mma16(fw[gk][i], fx[gk][i], acc[3]);
-            }
+            mma12_avv(acc[0], acc[1], acc[3], &wi[0][gk * 4], &wi[1][gk * 4], fw[gk], fx[gk]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
