@@ -80,6 +80,8 @@ constexpr int PG_PERSIST_SYNC_WORDS = PG_PERSIST_MAX_GROUPS * PG_MAX_LAYERS * 16
 // share an L2 (256 workgroups, the 16 on XCDs 6-7 idle).  Placement is a speed matter only.
 static inline int persist_groups(int L, int B) {
   auto tiles = [&](int ng) { return ((B + ng - 1) / ng + 15) / 16; };
+  static const int forced = getenv("PG_PERSIST_GROUPS") ? atoi(getenv("PG_PERSIST_GROUPS")) : 0;   // A/B aid: 8 or 10
+  if (forced == 8 || (forced == 10 && L == 3)) return forced;
   return (L == 3 && tiles(10) < tiles(8)) ? 10 : 8;
 }
 // workgroup -> (group, layer-order index k/NCU, slice); false: idle workgroup
