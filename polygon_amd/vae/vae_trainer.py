@@ -216,7 +216,7 @@ class VAETrainer:
         return torch.randn(batch.global_rows, dz, device=dev, generator=self._dgen)[rank::world].contiguous()
 
     def _prefetch(self, data_loader):
-        """Iterates ``data_loader`` on a background thread, ``prefetch`` batches ahead (default 2; 0 = in line): sampling,
+        """Iterates ``data_loader`` on a background thread, ``prefetch`` batches ahead (default 0 = in line): sampling,
         the length sort, tokenising and the pinned upload of batch i+1 overlap the GPU step of batch i (the launches are
         asynchronous and ctypes releases the GIL).  Order and contents are exactly the loader's."""
         depth = int(getattr(self, "prefetch", 0) or 0)
