@@ -124,8 +124,9 @@ def roofline_recurrence(dtype):
                                "flop_per_launch": fl_f / n_f, "achieved": fl_f / (ms_f * 1e-3) / 1e12,
                                "traffic": pmc_traffic(k_f, dtype)},
             "note": "the recurrence is a chain of T dependent steps of ~1-5 GFLOP each; inside the persistent launch a step is "
-                    "bounded by the inter-workgroup hand-off (~4 us) and by the L2 traffic of the all-gathered activations "
-                    "(96 KB per 16-row tile and workgroup, 8 GB per launch), not by MFMA throughput: DESIGN.md 3"}
+                    "~1.5 us of inter-workgroup hand-off plus ~3 us per 16-row tile - the tile's all-gathered activations (96 KB per "
+                    "workgroup out of L2, 8 GB per launch), its 96 MFMAs per wave, its gate epilogue and stores run as a chain "
+                    "that the 4-slot LDS ring cannot overlap with the next tile - not MFMA throughput: DESIGN.md 3, 7"}
 
 
 # ---- CPU baseline (SURVEY.md 8d protocol) ------------------------------------------------------------------------
