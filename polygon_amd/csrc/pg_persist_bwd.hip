@@ -371,27 +371,27 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
         epi_ld16(q_nh, sl, a.sv[l][2]);
         epi_ld8(q_hp, sidx * 2u, a.sv[l][4]);
       } else {
-      if (has_own && !(dbg & 4)) cr = *reinterpret_cast<const f32x4*>(carry + (long)bs * H + u0);
-      if (!fin && !(dbg & 4)) {
-        const long sidx = (long)(o + bs) * H + u0;
-        if constexpr (TOP) dtop = *reinterpret_cast<const f32x4*>(a.dout + sidx);
-        // lane order, as the forward kernel wrote them (pg_persist.h, sv_tile_slot)
-        if (sv_lane) {   // kernel-uniform: (r, z) and (n, hn) pairs, 16 bytes per lane each (pg_persist_dec.hip)
-          const long sl = ((sv_tile_slot(o, t, NG, j, g) * NCU + c) * 256 + wave * 64 + lane) * 8;
-          const u32x4 prz = *reinterpret_cast<const u32x4*>(a.sv[l][0] + sl);
-          const u32x4 pnh = *reinterpret_cast<const u32x4*>(a.sv[l][2] + sl);
-          svr = __builtin_bit_cast(bf16x4, u32x2{prz[0], prz[1]});
-          svz = __builtin_bit_cast(bf16x4, u32x2{prz[2], prz[3]});
-          svn = __builtin_bit_cast(bf16x4, u32x2{pnh[0], pnh[1]});
-          svhn = __builtin_bit_cast(bf16x4, u32x2{pnh[2], pnh[3]});
-        } else {
-          svr = *reinterpret_cast<const bf16x4*>(a.sv[l][0] + sidx);
-          svz = *reinterpret_cast<const bf16x4*>(a.sv[l][1] + sidx);
-          svn = *reinterpret_cast<const bf16x4*>(a.sv[l][2] + sidx);
-          svhn = *reinterpret_cast<const bf16x4*>(a.sv[l][3] + sidx);
+        if (has_own && !(dbg & 4)) cr = *reinterpret_cast<const f32x4*>(carry + (long)bs * H + u0);
+        if (!fin && !(dbg & 4)) {
+          const long sidx = (long)(o + bs) * H + u0;
+          if constexpr (TOP) dtop = *reinterpret_cast<const f32x4*>(a.dout + sidx);
+          // lane order, as the forward kernel wrote them (pg_persist.h, sv_tile_slot)
+          if (sv_lane) {   // kernel-uniform: (r, z) and (n, hn) pairs, 16 bytes per lane each (pg_persist_dec.hip)
+            const long sl = ((sv_tile_slot(o, t, NG, j, g) * NCU + c) * 256 + wave * 64 + lane) * 8;
+            const u32x4 prz = *reinterpret_cast<const u32x4*>(a.sv[l][0] + sl);
+            const u32x4 pnh = *reinterpret_cast<const u32x4*>(a.sv[l][2] + sl);
+            svr = __builtin_bit_cast(bf16x4, u32x2{prz[0], prz[1]});
+            svz = __builtin_bit_cast(bf16x4, u32x2{prz[2], prz[3]});
+            svn = __builtin_bit_cast(bf16x4, u32x2{pnh[0], pnh[1]});
+            svhn = __builtin_bit_cast(bf16x4, u32x2{pnh[2], pnh[3]});
+          } else {
+            svr = *reinterpret_cast<const bf16x4*>(a.sv[l][0] + sidx);
+            svz = *reinterpret_cast<const bf16x4*>(a.sv[l][1] + sidx);
+            svn = *reinterpret_cast<const bf16x4*>(a.sv[l][2] + sidx);
+            svhn = *reinterpret_cast<const bf16x4*>(a.sv[l][3] + sidx);
+          }
+          svhp = *reinterpret_cast<const bf16x4*>(a.sv[l][4] + sidx);
         }
-        svhp = *reinterpret_cast<const bf16x4*>(a.sv[l][4] + sidx);
-      }
       }
       f32x4 ah[2], au[2];
 #pragma unroll
