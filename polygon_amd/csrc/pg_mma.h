@@ -46,21 +46,23 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 // Four K-steps x three gates as ONE asm statement (12 MFMAs; accumulators %0-%2, weights %3-%14 gate-major, activation
 // fragments %15-%18): hipcc then waits once for the group's LDS fragments instead of once per single-MFMA asm, and the
 // per-MFMA nop goes (one wave per SIMD issues one instruction at a time: the 96 nops of a tile were an eighth of its
-// instructions).  Accumulation on one destination three MFMAs apart is interlocked by the hardware.  FIRST: the tile's
+// instructions).  Accumulation on one destination three MFMAs apart is interlocked by the hardware.  The `s_nop 0` between
+// the MFMAs is NOT a hazard nop: a lone wave that issues 16x16x32 MFMAs back to back gets one per 45 cycles (18.8 ns), with
+// any one instruction in between one per 33 cycles (13.8 ns; tools/mfma_rate.hip) - the matrix pipe's own rate.  FIRST: the tile's
 // first group, behind the VALU moves that zero the accumulators.  CA/CB/CC: register class of each gate's weights.
-#define PG_MMA12_BODY                                 \
-  "v_mfma_f32_16x16x32_bf16 %0, %3, %15, %0\n\t"      \
-  "v_mfma_f32_16x16x32_bf16 %1, %7, %15, %1\n\t"      \
-  "v_mfma_f32_16x16x32_bf16 %2, %11, %15, %2\n\t"     \
-  "v_mfma_f32_16x16x32_bf16 %0, %4, %16, %0\n\t"      \
-  "v_mfma_f32_16x16x32_bf16 %1, %8, %16, %1\n\t"      \
-  "v_mfma_f32_16x16x32_bf16 %2, %12, %16, %2\n\t"     \
-  "v_mfma_f32_16x16x32_bf16 %0, %5, %17, %0\n\t"      \
-  "v_mfma_f32_16x16x32_bf16 %1, %9, %17, %1\n\t"      \
-  "v_mfma_f32_16x16x32_bf16 %2, %13, %17, %2\n\t"     \
-  "v_mfma_f32_16x16x32_bf16 %0, %6, %18, %0\n\t"      \
-  "v_mfma_f32_16x16x32_bf16 %1, %10, %18, %1\n\t"     \
-  "v_mfma_f32_16x16x32_bf16 %2, %14, %18, %2"
+#define PG_MMA12_BODY                                              \
+  "v_mfma_f32_16x16x32_bf16 %0, %3, %15, %0\n\ts_nop 0\n\t"      \
+  "v_mfma_f32_16x16x32_bf16 %1, %7, %15, %1\n\ts_nop 0\n\t"      \
+  "v_mfma_f32_16x16x32_bf16 %2, %11, %15, %2\n\ts_nop 0\n\t"     \
+  "v_mfma_f32_16x16x32_bf16 %0, %4, %16, %0\n\ts_nop 0\n\t"      \
+  "v_mfma_f32_16x16x32_bf16 %1, %8, %16, %1\n\ts_nop 0\n\t"      \
+  "v_mfma_f32_16x16x32_bf16 %2, %12, %16, %2\n\ts_nop 0\n\t"     \
+  "v_mfma_f32_16x16x32_bf16 %0, %5, %17, %0\n\ts_nop 0\n\t"      \
+  "v_mfma_f32_16x16x32_bf16 %1, %9, %17, %1\n\ts_nop 0\n\t"      \
+  "v_mfma_f32_16x16x32_bf16 %2, %13, %17, %2\n\ts_nop 0\n\t"     \
+  "v_mfma_f32_16x16x32_bf16 %0, %6, %18, %0\n\ts_nop 0\n\t"      \
+  "v_mfma_f32_16x16x32_bf16 %1, %10, %18, %1\n\ts_nop 0\n\t"     \
+  "v_mfma_f32_16x16x32_bf16 %2, %14, %18, %2\n\ts_nop 0"
 #define PG_MMA12_OPS(CA, CB, CC)                                                                                         \
   : "+v"(c0), "+v"(c1), "+v"(c2)                                                                                         \
   : CA(wa[0]), CA(wa[1]), CA(wa[2]), CA(wa[3]), CB(wb[0]), CB(wb[1]), CB(wb[2]), CB(wb[3]), CC(wc[0]), CC(wc[1]), CC(wc[2]), \

@@ -48,13 +48,15 @@ __device__ __forceinline__ f32x4 mma16a_nn(const bf16x8& w, const bf16x8& x, f32
 // A group of four K-steps as ONE asm statement: hipcc then waits once for the group's four LDS fragments (left alone it puts
 // an exact lgkmcnt wait in front of every single-MFMA asm, and a nop between asm statements that share an accumulator) -
 // ~100 fewer instructions per tile.  Accumulation on the same destination two MFMAs apart is interlocked by the hardware.
+// The `s_nop 0` between the MFMAs is not a hazard nop: back-to-back 16x16x32 MFMAs of a lone wave issue every 45 cycles, with
+// one instruction in between every 33 (tools/mfma_rate.hip).
 // FIRST: the tile's first group, whose accumulators were just zeroed by VALU moves (2 wait states).  WA: the weight fragments
 // live in AGPRs ("a") or in VGPRs / come from LDS ("v").
-#define PG_MMA4_BODY                                 \
-  "v_mfma_f32_16x16x32_bf16 %0, %2, %6, %0\n\t"      \
-  "v_mfma_f32_16x16x32_bf16 %1, %3, %7, %1\n\t"      \
-  "v_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n\t"      \
-  "v_mfma_f32_16x16x32_bf16 %1, %5, %9, %1"
+#define PG_MMA4_BODY                                               \
+  "v_mfma_f32_16x16x32_bf16 %0, %2, %6, %0\n\ts_nop 0\n\t"       \
+  "v_mfma_f32_16x16x32_bf16 %1, %3, %7, %1\n\ts_nop 0\n\t"       \
+  "v_mfma_f32_16x16x32_bf16 %0, %4, %8, %0\n\ts_nop 0\n\t"       \
+  "v_mfma_f32_16x16x32_bf16 %1, %5, %9, %1\n\ts_nop 0"
 template <bool FIRST, bool WA>
 __device__ __forceinline__ void mma16_x4(f32x4& c0, f32x4& c1, const bf16x8& w0, const bf16x8& w1, const bf16x8& w2,
                                          const bf16x8& w3, const bf16x8& x0, const bf16x8& x1, const bf16x8& x2, const bf16x8& x3) {
