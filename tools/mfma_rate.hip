@@ -31,6 +31,22 @@ __global__ __launch_bounds__(256) void rate_kernel(float* out, int iters) {
       for (int k = 0; k < 8; ++k) c[k] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4, b4, c[k], 0, 0, 0);
     }
     for (int k = 0; k < 8; ++k) s += c[k][0];
+  } else if constexpr (KIND == 20) {
+    f32x16 c[8];
+    for (int k = 0; k < 8; ++k)
+      for (int e = 0; e < 16; ++e) c[k][e] = 0.f;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    u32x4 ra, rb;
+    unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+    for (int i = 0; i < 4; ++i) { h = h * 1664525u + 1013904223u; ra[i] = (h & 0x7fff7fffu) | 0x30003000u; h = h * 1664525u + 1013904223u; rb[i] = (h & 0x7fff7fffu) | 0x30003000u; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        c[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra), __builtin_bit_cast(bf16x8, rb), c[k], 0, 0, 0);
+        ra[k & 3] ^= 0x00550055u << (k & 7);      // one VALU per MFMA: operands keep changing
+      }
+    }
+    for (int k = 0; k < 8; ++k) s += c[k][0];
   } else if constexpr (KIND >= 10) {   // 16x16x32 with a filler between MFMAs
     f32x4 c[8];
     for (int k = 0; k < 8; ++k) c[k] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -94,7 +110,7 @@ static void run(const char* name, int grid, int block, int iters) {
   hipEventElapsedTime(&ms, e0, e1);
   const int waves_per_simd = block / 64 / 4 > 0 ? block / 64 / 4 : 1;
   const double n_per_simd = (double)iters * 8 * waves_per_simd;
-  const double flop = (KIND == 2 ? 2.0 * 16 * 16 * 16 : KIND == 1 ? 2.0 * 32 * 32 * 16 : 2.0 * 16 * 16 * 32) * iters * 8.0 * (block / 64) * grid;
+  const double flop = (KIND == 2 ? 2.0 * 16 * 16 * 16 : (KIND == 1 || KIND == 20) ? 2.0 * 32 * 32 * 16 : 2.0 * 16 * 16 * 32) * iters * 8.0 * (block / 64) * grid;
   printf("%-22s grid %4d block %4d: %.3f ms, %.2f ns per MFMA and SIMD, %.1f TFLOP/s\n", name, grid, block, ms,
          ms * 1e6 / n_per_simd, flop / (ms * 1e-3) / 1e12);
   hipFree(d);
@@ -116,6 +132,9 @@ int main() {
   run<1>("32x32x16 bf16", 1, 256, iters);
   run<0>("16x16x32 bf16", 256, 256, iters);    // one wave per SIMD on every CU
   run<1>("32x32x16 bf16", 256, 256, iters);
+  run<20>("32x32x16 random data", 1, 256, iters);
+  run<20>("32x32x16 random data", 256, 256, iters);
+  run<20>("32x32x16 random data", 192, 256, iters);
   run<0>("16x16x32 bf16", 1024, 256, iters);   // four workgroups per CU = four waves per SIMD: divide the ns by 4
   run<1>("32x32x16 bf16", 1024, 256, iters);
   return 0;
