@@ -57,6 +57,28 @@ def test_persistent_matches_per_step(n, p_drop):
     assert rel_err(a[2], b[2]) <= 1e-4
 
 
+@pytest.mark.parametrize("layers,p_drop", [(2, 0.2), (4, 0.2), (1, 0.0)])
+def test_persistent_other_layer_counts(layers, p_drop):
+    """Decoders with 2 and 4 layers (no middle layer / two of them: the compile-time layer kinds of the training
+    instantiation of the recurrences) and the 1-layer decoder (generic instantiation): persistent against per-step."""
+    from polygon_amd.vae.vae_trainer import FusedClipAdam
+    dims = dict(REAL, L=layers)
+    model, _ = build_model(dims, 33, "bf16", d_dropout=p_drop)
+    model.train()
+    n = 200
+    batch = model.get_collate_fn()(list(O.synthetic_smiles(n, seed=layers)))
+    eps = torch.from_numpy(np.random.default_rng(layers).standard_normal((n, REAL["Dz"])).astype(np.float32)).cuda()
+    opt = FusedClipAdam(model, lr=0.0)
+    ref = _run(model, opt, batch, eps, p_drop, 7)
+    got = _run(model, opt, batch, eps, p_drop, 0)
+    assert abs(got[0] - ref[0]) <= 2e-3 * abs(ref[0]) and abs(got[1] - ref[1]) <= 2e-3 * abs(ref[1])
+    off = 0
+    for i, p in enumerate(model._engine.params()):
+        k = p.numel()
+        assert rel_err(got[2][off:off + k], ref[2][off:off + k]) <= 5e-3, (layers, i, tuple(p.shape))
+        off += k
+
+
 def _sample(model, mask, n, **kw):
     L = _lib.lib()
     old = L.pg_persist_disable(mask)
