@@ -450,7 +450,12 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void fc_ce_kernel(const typename Cfg
   constexpr int NW = Cfg::NTHREADS / 64;
   const float bias = lane < Vp ? fcb[lane] : 0.0f;
   float loss = 0.0f, cnt = 0.0f;
-  for (int r = wave; r < Cfg::BM; r += NW) {
+  // the targets of this wave's rows in ONE load (lane k: the row of iteration k): a load per iteration put a memory round
+  // trip on every row
+  static_assert(Cfg::BM / NW <= 64, "one lane per iteration");
+  const long my_row = (long)m0 + wave + lane * NW;
+  const int tg_all = (lane < Cfg::BM / NW && my_row < N) ? tgt[my_row] : pad;
+  for (int r = wave, it = 0; r < Cfg::BM; r += NW, ++it) {
     const long row = (long)m0 + r;
     if (row >= N) break;
     const float y = sl[r * 65 + lane] + bias;
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void fc_ce_kernel(const typename Cfg
     const float mx = wave_max(x);
     const float e = lane < V ? __expf(x - mx) : 0.0f;
     const float s = wave_sum(e);
-    const int tg = tgt[row];
+    const int tg = __builtin_amdgcn_readlane(tg_all, it);
     const bool w = tg != pad;
     const float xt = __shfl(x, tg < 64 ? tg : 0, 64);
     if (w) { loss += __logf(s) + mx - xt; cnt += 1.0f; }
@@ -592,8 +597,10 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
   }
   prof_end(0, pslot, st, sd.T + L - 1, pflop);
   if (Vp == 64 && !getenv("PG_NO_FUSED_CE")) {   // vocab projection + log-softmax + CE + dlogits in one kernel
-    using FCfg = TileCfg<T, 128, 64, 8, 4, 1>;
-    static_assert(FCfg::SMEM_BYTES >= 128 * 65 * 4, "fc_ce kernel: LDS too small for the logits tile");
+    // K = 512 is a latency chain of 8 K tiles per block: two of them in flight and eight waves (16 epilogue rows per wave
+    // instead of 32) took the kernel from 52 to 36 us; four in flight, or 64-row blocks, measured slower
+    using FCfg = TileCfg<T, 128, 64, 8, 4, 2, 1, 2>;
+    static_assert(FCfg::SMEM_BYTES >= FCfg::BM * 65 * 4, "fc_ce kernel: LDS too small for the logits tile");
     PG_LAUNCH_BIG_SMEM(fc_ce_kernel<FCfg>, dim3(cdiv(Nd, FCfg::BM)), dim3(FCfg::NTHREADS), FCfg::SMEM_BYTES, st,
                        at<T>(ws, w.d_hseq[L - 1]), Nd, Hd, at<T>(shadow, so.fc_w), at<float>(shadow, so.fc_b), d->V, Vp,
                        at<int>(ws, w.dec_tgt), d->pad, logits_packed ? at<float>(ws, w.d_logits) : (float*)nullptr,   // logits only when the caller takes them
