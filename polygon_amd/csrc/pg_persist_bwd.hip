@@ -161,12 +161,12 @@ __device__ __forceinline__ void wait_parts(int younger) {
   }
 }
 
-// development aid: workgroup (g 0, traced layer, slice 0) records wall-clock stamps (100 MHz) of its steps 8..15.  Stamps and
+// development aid: workgroup (traced group stamps[2], traced layer, slice 0) records wall-clock stamps (100 MHz) of its steps 8..15.  Stamps and
 // the knock-out switches (PG_PERSIST_DBG) live in the DBG instantiation only: as run-time tests they cost the production
 // kernel 6-8 scalar branches per part.
 #define PG_STAMP(slot)                                                                                   \
   do {                                                                                                   \
-    if (DBG && a.stamps && tid == 0 && g == 0 && c == 0 && l == (int)a.stamps[0] && s >= (int)a.stamps[1] && s < (int)a.stamps[1] + 8) \
+    if (DBG && a.stamps && tid == 0 && g == (int)a.stamps[2] && c == 0 && l == (int)a.stamps[0] && s >= (int)a.stamps[1] && s < (int)a.stamps[1] + 8) \
       a.stamps[8 + (s - (int)a.stamps[1]) * 8 + (slot)] = wall_clock64();                                               \
   } while (0)
 

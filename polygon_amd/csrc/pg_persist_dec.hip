@@ -81,7 +81,7 @@ __device__ __forceinline__ bool wait_ge(unsigned* p, unsigned target, unsigned* 
 // development aid: workgroup (g 0, layer STAMP_L, slice 0) records wall-clock stamps (100 MHz) of steps 8..15, 8 slots each
 #define PG_STAMP(slot)                                                                                   \
   do {                                                                                                   \
-    if (DBG && a.stamps && tid == 0 && g == 0 && c == 0 && l == (int)a.stamps[0] && t >= (int)a.stamps[1] && t < (int)a.stamps[1] + 8) \
+    if (DBG && a.stamps && tid == 0 && g == (int)a.stamps[2] && c == 0 && l == (int)a.stamps[0] && t >= (int)a.stamps[1] && t < (int)a.stamps[1] + 8) \
       a.stamps[8 + (t - (int)a.stamps[1]) * 8 + (slot)] = wall_clock64();                                               \
   } while (0)
 
