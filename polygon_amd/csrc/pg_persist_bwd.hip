@@ -60,17 +60,12 @@ __device__ __forceinline__ f32x4 mma16a_nn(const bf16x8& w, const bf16x8& x, f32
 template <bool FIRST, bool WA>
 __device__ __forceinline__ void mma16_x4(f32x4& c0, f32x4& c1, const bf16x8& w0, const bf16x8& w1, const bf16x8& w2,
                                          const bf16x8& w3, const bf16x8& x0, const bf16x8& x1, const bf16x8& x2, const bf16x8& x3) {
-  if constexpr (WA) {
-    if constexpr (FIRST)
-      asm("s_nop 1\n\t" PG_MMA4_BODY : "+v"(c0), "+v"(c1) : "a"(w0), "a"(w1), "a"(w2), "a"(w3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
-    else
-      asm(PG_MMA4_BODY : "+v"(c0), "+v"(c1) : "a"(w0), "a"(w1), "a"(w2), "a"(w3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
-  } else {
-    if constexpr (FIRST)
-      asm("s_nop 1\n\t" PG_MMA4_BODY : "+v"(c0), "+v"(c1) : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
-    else
-      asm(PG_MMA4_BODY : "+v"(c0), "+v"(c1) : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
-  }
+  // every group starts with `s_nop 1`, not only a tile's first: hipcc may set up an operand with a VALU move right in
+  // front of the statement (tools/check_mfma_hazard.py found such a case in the forward kernel)
+  if constexpr (WA)
+    asm("s_nop 1\n\t" PG_MMA4_BODY : "+v"(c0), "+v"(c1) : "a"(w0), "a"(w1), "a"(w2), "a"(w3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+  else
+    asm("s_nop 1\n\t" PG_MMA4_BODY : "+v"(c0), "+v"(c1) : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
 }
 // matrix-pipe write -> VALU read wait states; tied to the accumulators so that every MFMA asm is ordered before it
 #define PG_MFMA_DRAIN(a0, a1, a2, a3) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3))
