@@ -67,18 +67,24 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
   : "+v"(c0), "+v"(c1), "+v"(c2)                                                                                         \
   : CA(wa[0]), CA(wa[1]), CA(wa[2]), CA(wa[3]), CB(wb[0]), CB(wb[1]), CB(wb[2]), CB(wb[3]), CC(wc[0]), CC(wc[1]), CC(wc[2]), \
     CC(wc[3]), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3])
-// all three gates' weights in AGPRs (the recurrent half).  Every group starts with `s_nop 1`: hipcc is free to set up an operand of the statement with a VALU move right in front of
-// it (it does, in some instantiations - tools/check_mfma_hazard.py found one), and a VALU write needs two wait states
-// before an MFMA reads the register.  One nop per 12 MFMAs.
-template <bool FIRST>
+// NOP: the statement starts with `s_nop 1` - for a tile's first group (its accumulators were just zeroed by VALU moves, and
+// a VALU write needs two wait states before an MFMA reads the register) and for EVERY group of the instrumented
+// instantiations, where hipcc sets up operands with VALU moves right in front of a statement (tools/check_mfma_hazard.py,
+// run by tests/test_isa_hazards.py over every instantiation, found one there).  In the production instantiations a nop per
+// group measured +10 us per kernel, so they carry it only where the listing check needs it.
+// all three gates' weights in AGPRs (the recurrent half)
+template <bool NOP>
 __device__ __forceinline__ void mma12_aaa(f32x4& c0, f32x4& c1, f32x4& c2, const bf16x8* wa, const bf16x8* wb, const bf16x8* wc,
                                           const bf16x8* x) {
-  asm("s_nop 1\n\t" PG_MMA12_BODY PG_MMA12_OPS("a", "a", "a"));
+  if constexpr (NOP) asm("s_nop 1\n\t" PG_MMA12_BODY PG_MMA12_OPS("a", "a", "a"));
+  else asm(PG_MMA12_BODY PG_MMA12_OPS("a", "a", "a"));
 }
 // input half: r weights in AGPRs, z weights in VGPRs, n weights read from LDS
+template <bool NOP>
 __device__ __forceinline__ void mma12_avv(f32x4& c0, f32x4& c1, f32x4& c2, const bf16x8* wa, const bf16x8* wb, const bf16x8* wc,
                                           const bf16x8* x) {
-  asm("s_nop 1\n\t" PG_MMA12_BODY PG_MMA12_OPS("a", "v", "v"));
+  if constexpr (NOP) asm("s_nop 1\n\t" PG_MMA12_BODY PG_MMA12_OPS("a", "v", "v"));
+  else asm(PG_MMA12_BODY PG_MMA12_OPS("a", "v", "v"));
 }
 
 template <typename T> struct MmaOp;

@@ -60,12 +60,18 @@ __device__ __forceinline__ f32x4 mma16a_nn(const bf16x8& w, const bf16x8& x, f32
 template <bool FIRST, bool WA>
 __device__ __forceinline__ void mma16_x4(f32x4& c0, f32x4& c1, const bf16x8& w0, const bf16x8& w1, const bf16x8& w2,
                                          const bf16x8& w3, const bf16x8& x0, const bf16x8& x1, const bf16x8& x2, const bf16x8& x3) {
-  // every group starts with `s_nop 1`, not only a tile's first: hipcc may set up an operand with a VALU move right in
-  // front of the statement (tools/check_mfma_hazard.py found such a case in the forward kernel)
-  if constexpr (WA)
-    asm("s_nop 1\n\t" PG_MMA4_BODY : "+v"(c0), "+v"(c1) : "a"(w0), "a"(w1), "a"(w2), "a"(w3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
-  else
-    asm("s_nop 1\n\t" PG_MMA4_BODY : "+v"(c0), "+v"(c1) : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+  // FIRST also for every group of the instrumented instantiations (pg_mma.h, mma12_aaa)
+  if constexpr (WA) {
+    if constexpr (FIRST)
+      asm("s_nop 1\n\t" PG_MMA4_BODY : "+v"(c0), "+v"(c1) : "a"(w0), "a"(w1), "a"(w2), "a"(w3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+    else
+      asm(PG_MMA4_BODY : "+v"(c0), "+v"(c1) : "a"(w0), "a"(w1), "a"(w2), "a"(w3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+  } else {
+    if constexpr (FIRST)
+      asm("s_nop 1\n\t" PG_MMA4_BODY : "+v"(c0), "+v"(c1) : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+    else
+      asm(PG_MMA4_BODY : "+v"(c0), "+v"(c1) : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(x0), "v"(x1), "v"(x2), "v"(x3));
+  }
 }
 // matrix-pipe write -> VALU read wait states; tied to the accumulators so that every MFMA asm is ordered before it
 #define PG_MFMA_DRAIN(a0, a1, a2, a3) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3))
@@ -415,7 +421,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
             __builtin_amdgcn_sched_barrier(0);
             const int k0 = p * 16 + gk * 4;
             if (p == 0 && gk == 0) mma16_x4<true, true>(ah[0], ah[1], wh[k0], wh[k0 + 1], wh[k0 + 2], wh[k0 + 3], f[gk][0], f[gk][1], f[gk][2], f[gk][3]);
-            else mma16_x4<false, true>(ah[0], ah[1], wh[k0], wh[k0 + 1], wh[k0 + 2], wh[k0 + 3], f[gk][0], f[gk][1], f[gk][2], f[gk][3]);
+            else mma16_x4<DBG, true>(ah[0], ah[1], wh[k0], wh[k0 + 1], wh[k0 + 2], wh[k0 + 3], f[gk][0], f[gk][1], f[gk][2], f[gk][3]);
             __builtin_amdgcn_sched_barrier(0);
           }
         };
@@ -445,8 +451,8 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
               __builtin_amdgcn_sched_barrier(0);
               const int k0 = p * 16 + gk * 4;
               if (p == 0 && gk == 0) mma16_x4<true, true>(au[0], au[1], wu[k0], wu[k0 + 1], wu[k0 + 2], wu[k0 + 3], f[gk][0], f[gk][1], f[gk][2], f[gk][3]);
-              else if (p == 0) mma16_x4<false, true>(au[0], au[1], wu[k0], wu[k0 + 1], wu[k0 + 2], wu[k0 + 3], f[gk][0], f[gk][1], f[gk][2], f[gk][3]);
-              else mma16_x4<false, false>(au[0], au[1], wu[k0], wu[k0 + 1], wu[k0 + 2], wu[k0 + 3], f[gk][0], f[gk][1], f[gk][2], f[gk][3]);
+              else if (p == 0) mma16_x4<DBG, true>(au[0], au[1], wu[k0], wu[k0 + 1], wu[k0 + 2], wu[k0 + 3], f[gk][0], f[gk][1], f[gk][2], f[gk][3]);
+              else mma16_x4<DBG, false>(au[0], au[1], wu[k0], wu[k0 + 1], wu[k0 + 2], wu[k0 + 3], f[gk][0], f[gk][1], f[gk][2], f[gk][3]);
               __builtin_amdgcn_sched_barrier(0);
             }
           };
@@ -480,8 +486,8 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
                 }
               }
               __builtin_amdgcn_sched_barrier(0);
-              if (gk & 1) mma16_x4<false, false>(au[0], au[1], wb[0], wb[1], wb[2], wb[3], xb[0], xb[1], xb[2], xb[3]);
-              else mma16_x4<false, false>(au[0], au[1], wa[0], wa[1], wa[2], wa[3], xa[0], xa[1], xa[2], xa[3]);
+              if (gk & 1) mma16_x4<DBG, false>(au[0], au[1], wb[0], wb[1], wb[2], wb[3], xb[0], xb[1], xb[2], xb[3]);
+              else mma16_x4<DBG, false>(au[0], au[1], wa[0], wa[1], wa[2], wa[3], xa[0], xa[1], xa[2], xa[3]);
               __builtin_amdgcn_sched_barrier(0);
             }
             }

@@ -308,7 +308,7 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
           }
           __builtin_amdgcn_sched_barrier(0);
           if (gk == 0) mma12_aaa<true>(acc[0], acc[1], acc[2], &wh[0][gk * 4], &wh[1][gk * 4], &wh[2][gk * 4], f[gk]);
-          else mma12_aaa<false>(acc[0], acc[1], acc[2], &wh[0][gk * 4], &wh[1][gk * 4], &wh[2][gk * 4], f[gk]);
+          else mma12_aaa<DBG>(acc[0], acc[1], acc[2], &wh[0][gk * 4], &wh[1][gk * 4], &wh[2][gk * 4], f[gk]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -332,7 +332,8 @@ __device__ __forceinline__ void dec_fwd_body(const DecFwdPersist& a, const Sched
             }
           }
           __builtin_amdgcn_sched_barrier(0);
-          mma12_avv(acc[0], acc[1], acc[3], &wi[0][gk * 4], &wi[1][gk * 4], fw[gk], fx[gk]);
+          if (gk == 0) mma12_avv<true>(acc[0], acc[1], acc[3], &wi[0][gk * 4], &wi[1][gk * 4], fw[gk], fx[gk]);   // acc[3] starts here
+          else mma12_avv<DBG>(acc[0], acc[1], acc[3], &wi[0][gk * 4], &wi[1][gk * 4], fw[gk], fx[gk]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }

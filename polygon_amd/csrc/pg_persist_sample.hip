@@ -316,7 +316,8 @@ __device__ __forceinline__ void layer_body(const DecSamplePersist& a, int g, int
               }
             }
             __builtin_amdgcn_sched_barrier(0);
-            mma12_avv(acc[0], acc[1], acc[3], &wi[0][gk * 4], &wi[1][gk * 4], fw[gk], fx[gk]);
+            if (gk == 0) mma12_avv<true>(acc[0], acc[1], acc[3], &wi[0][gk * 4], &wi[1][gk * 4], fw[gk], fx[gk]);   // acc[3] starts here
+            else mma12_avv<false>(acc[0], acc[1], acc[3], &wi[0][gk * 4], &wi[1][gk * 4], fw[gk], fx[gk]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
