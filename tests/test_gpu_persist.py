@@ -79,6 +79,23 @@ def test_persistent_other_layer_counts(layers, p_drop):
         off += k
 
 
+def test_training_instantiation_matches_generic(monkeypatch):
+    """The recurrences' compile-time training configuration (FAST) against their generic instantiation on the same step:
+    same arithmetic in the same order, so losses agree to the last bits and gradients to the atomics' rounding."""
+    from polygon_amd.vae.vae_trainer import FusedClipAdam
+    model, _ = build_model(REAL, 5, "bf16", d_dropout=0.2)
+    model.train()
+    n = 333
+    batch = model.get_collate_fn()(list(O.synthetic_smiles(n, seed=9)))
+    eps = torch.from_numpy(np.random.default_rng(9).standard_normal((n, REAL["Dz"])).astype(np.float32)).cuda()
+    opt = FusedClipAdam(model, lr=0.0)
+    fast = _run(model, opt, batch, eps, 0.2, 0)
+    monkeypatch.setenv("PG_PERSIST_NO_FAST", "1")
+    generic = _run(model, opt, batch, eps, 0.2, 0)
+    assert abs(fast[0] - generic[0]) <= 1e-6 * abs(generic[0]) and abs(fast[1] - generic[1]) <= 1e-6 * abs(generic[1])
+    assert rel_err(fast[2], generic[2]) <= 1e-4
+
+
 def _sample(model, mask, n, **kw):
     L = _lib.lib()
     old = L.pg_persist_disable(mask)
