@@ -21,15 +21,79 @@ import ctypes
 import json
 import os
 import platform
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def build_parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--n_batch", type=int, default=1024, help="batch per GPU (weak) / global batch (strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--dropout", type=float, default=0.2)
+    ap.add_argument("--sample_n", type=int, default=8192, help="molecules per GPU in the sampling leg (0 = skip)")
+    ap.add_argument("--sample_extra", default="65536,1048576", help="more row counts for the sampling leg at N = 1")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_roofline", action="store_true")
+    ap.add_argument("--no_e2e", action="store_true")
+    ap.add_argument("--no_other_scaling", action="store_true")
+    ap.add_argument("--no_proxy", action="store_true")
+    ap.add_argument("--no_configs0", action="store_true", help="skip the fp32 configs[0] leg (n_batch 512)")
+    ap.add_argument("--launch_check", action="store_true",
+                    help="only start the ranks, form the process group, report rank/world per child and exit (no GPU work)")
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"], help="default: nccl (= RCCL) when every rank has a GPU")
+    return ap
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: start N fresh interpreters of this file, one per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1), relay rank 0's JSON line and fail if any rank
+    fails.  Runs BEFORE torch or polygon_amd are imported: the parent never touches the GPU, and the children are plain
+    subprocesses, never an exec of a process that has initialised HIP.  (The reference has no counterpart:
+    polygon/run.py:611-612 is a comment.)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PG_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = None if r == 0 else sys.stderr          # rank 0 prints the JSON line on the parent's stdout
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    rc = 0
+    pending = set(range(args.gpus))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print("bench.py: rank %d exited with %d; stopping the other ranks" % (r, code), file=sys.stderr)
+                for q in pending:
+                    procs[q].terminate()             # exact children only
+        time.sleep(0.05)
+    return rc
+
+
+if __name__ == "__main__":
+    _args = build_parser().parse_args()
+    if _args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(_args))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 from polygon_amd import _lib  # noqa: E402
 from polygon_amd.parallel import GradComm, init_distributed  # noqa: E402
@@ -174,7 +238,7 @@ def cpu_baseline():
     nthreads = int(os.environ.get("OMP_NUM_THREADS", 0)) or min(cores, 16)
     torch.set_num_threads(nthreads)
     P = O.init_params(seed=0)
-    n_train = 256
+    n_train = 512          # configs[0]'s batch
     seqs = O.collate(O.synthetic_smiles(n_train, seed=1))
     ntok = sum(len(s) for s in seqs)
     ts_ = TC.to_tensors(seqs)
@@ -301,6 +365,35 @@ def e2e_leg(args, dev, rank, world, barrier):
                     "fused step, epoch-end loss read-back; each rank tokenises only its shard"}
 
 
+def configs0_leg(dev, barrier):
+    """BASELINE.json configs[0] on the GPU at the reference's own precision: the MOSES-default VAE in fp32 (the reference's
+    arithmetic, vae_model.py:66-98), n_batch 512, 10 000 synthetic strings, d_dropout 0.2 (the `polygon train` default,
+    run.py:372-374): one `VAETrainer.fit` epoch (20 batches, the last of 272 strings) and the resident-batch step."""
+    nb = 512
+    strings = synthetic_smiles(10000, seed=20250310)
+    ntok = sum(map(len, strings)) + 2 * len(strings)
+    torch.manual_seed(0)
+    model = VAE(d_dropout=0.2, compute_dtype="fp32").to(dev).train()
+    opt = FusedClipAdam(model, lr=3e-4, clip_grad=50)
+    eng = model._engine
+    eng.ensure_shadow()
+    pool = make_pool(model, strings, nb, 0, 1, 8, dev)
+    d, t = time_steps(eng, opt, pool, None, 0.2, 20, 3, barrier)
+    kw = dict(n_batch=nb, n_epoch=1, kl_start=0, kl_w_start=0.5, model_save=None, log_file=None)
+    VAETrainer(model, **kw).fit(list(strings[:4 * nb]))          # warm-up
+    barrier()
+    t0 = time.perf_counter()
+    VAETrainer(model, **kw).fit(list(strings))
+    barrier()
+    dt = time.perf_counter() - t0
+    return {"workload": "configs[0]: MOSES-default SMILES VAE, fp32, n_batch 512, d_dropout 0.2, 10 000 synthetic strings",
+            "dtype": "fp32", "n_batch": nb,
+            "resident_step": {"ms_per_step": d / 20 * 1e3, "tokens_per_s": t / d,
+                              "frac_of_fp32_matrix_peak": t / d * TRAIN_FLOP_PER_TOKEN / 1e12 / PEAK["fp32"]},
+            "fit_epoch": {"strings": len(strings), "tokens": ntok, "s_per_epoch": dt, "tokens_per_s": ntok / dt},
+            "kernels": "per-step gru_fwd2/gru_bwd2 diagonals on v_mfma_f32_32x32x2_f32 (the persistent recurrences are bf16-only)"}
+
+
 def sample_leg(model, n, rank, world, dev, barrier, reps=3, all_steps=False):
     """n rows per GPU, max_len 100: token matrix + end positions INCLUDING the D2H copy (SURVEY.md 8d metric 2).
     Rows that have drawn their eos leave the decode (pg_persist_sample.hip, build_live_list); ``all_steps`` switches that
@@ -335,27 +428,42 @@ def sample_leg(model, n, rank, world, dev, barrier, reps=3, all_steps=False):
             "tflops": mol_s * SAMPLE_FLOP_PER_MOL * steps_run / 99.0 / 1e12}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--n_batch", type=int, default=1024, help="batch per GPU (weak) / global batch (strong)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--dropout", type=float, default=0.2)
-    ap.add_argument("--sample_n", type=int, default=8192, help="molecules per GPU in the sampling leg (0 = skip)")
-    ap.add_argument("--sample_extra", default="65536,1048576", help="more row counts for the sampling leg at N = 1")
-    ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--no_roofline", action="store_true")
-    ap.add_argument("--no_e2e", action="store_true")
-    ap.add_argument("--no_other_scaling", action="store_true")
-    ap.add_argument("--no_proxy", action="store_true")
-    args = ap.parse_args()
+def launch_check(args):
+    """Every rank joins the process group and reports (rank, world, local rank, pid); rank 0 prints them as ONE JSON line."""
+    import torch.distributed as dist
+    if os.environ.get("PG_BENCH_FAIL_RANK") == os.environ.get("RANK", "0"):      # test hook: this rank fails before the rendezvous
+        sys.exit(7)
+    want_nccl = args.backend == "nccl" or (args.backend is None and torch.cuda.is_available()
+                                           and torch.cuda.device_count() >= int(os.environ.get("WORLD_SIZE", "1")))
+    rank, world, local = init_distributed("nccl" if want_nccl else "gloo")
+    me = [rank, world, local, os.getpid()]
+    if world > 1:
+        got = [None] * world
+        dist.all_gather_object(got, me)
+    else:
+        got = [me]
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "requested_gpus": args.gpus, "world": world,
+                          "backend": dist.get_backend() if world > 1 else None,
+                          "rccl_ranks": world if world > 1 and dist.get_backend() == "nccl" else 0,
+                          "self_launched": os.environ.get("PG_BENCH_SELF_LAUNCHED") == "1",
+                          "ranks": [{"rank": r, "world": w, "local_rank": lr, "pid": p} for r, w, lr, p in got]}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if world == args.gpus else 3
 
-    rank, world, local = init_distributed()
-    if world != args.gpus and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+
+def main():
+    args = build_parser().parse_args()
+    if args.launch_check:
+        sys.exit(launch_check(args))
+
+    rank, world, local = init_distributed(args.backend)
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but the process group has %d ranks" % (args.gpus, world), file=sys.stderr)
+        sys.exit(3)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.manual_seed(0)
@@ -405,6 +513,9 @@ def main():
     e2e = None
     if not args.no_e2e:
         e2e = e2e_leg(args, dev, rank, world, barrier)
+    configs0 = None
+    if world == 1 and not args.no_configs0:
+        configs0 = configs0_leg(dev, barrier)
 
     # ---- sampling leg (configs[3]): per-GPU shard, no collective during decode --------------------------------
     sample = None
@@ -433,6 +544,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "vae_train_tokens_per_sec", "value": tok_per_s, "unit": "tokens/s", "n_gpus": world,
+            "rccl_ranks": world if world > 1 and torch.distributed.get_backend() == "nccl" else 0,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "configs[1]: MOSES-default SMILES VAE (GRU enc 256, 3xGRU dec 512, d_z 128, vocab 51) "
@@ -452,6 +564,8 @@ def main():
             out["strong_scaling_proxy"] = proxy
         if e2e is not None:
             out["e2e"] = e2e
+        if configs0 is not None:
+            out["configs0"] = configs0
         if roofline is not None:
             out["roofline"] = roofline
             out["roofline"]["single_cell_microbench"] = step_kernel_microbench(args.dtype, args.n_batch, 512)

@@ -74,3 +74,33 @@ def test_data_parallel_plumbing_gloo(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+def _launch_check(n):
+    """`python bench.py --gpus n --launch_check` with no torchrun environment: the file starts n ranks by itself."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--launch_check", "--backend", "gloo"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_self_launch_two_ranks():
+    out = _launch_check(2)
+    assert out["launch_check"] and out["world"] == 2 and out["requested_gpus"] == 2 and out["self_launched"]
+    assert sorted(r["rank"] for r in out["ranks"]) == [0, 1]
+    assert sorted(r["local_rank"] for r in out["ranks"]) == [0, 1]
+    assert all(r["world"] == 2 for r in out["ranks"])
+    assert len({r["pid"] for r in out["ranks"]}) == 2          # two distinct child interpreters
+
+
+def test_bench_self_launch_propagates_failure():
+    """A rank that fails makes the launcher exit non-zero (here: an argument the children reject)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["PG_BENCH_FAIL_RANK"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch_check", "--backend", "gloo"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
