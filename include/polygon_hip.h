@@ -14,11 +14,15 @@
  *
  * Library-owned state (process-wide, NOT thread-safe: one process per GPU, one calling thread at a
  * time is the model): (1) a 64-byte device word + 64-byte pinned host mirror "a persistent kernel
- * gave up", allocated on the first persistent launch and never freed; (2) the side stream and two
- * events of pg_defer_weight_grads, created on first use; (3) up to 2 x 512 HIP event pairs while
- * pg_profile_enable is on; (4) the switches set by pg_persist_disable / pg_defer_weight_grads /
- * pg_profile_enable / pg_persist_spin_limit (read once from PG_NO_PERSIST at first use); (5) the 2-KiB
- * static device array of pg_clip_adam_static.  Nothing else persists between calls.
+ * gave up", allocated on the first persistent launch and never freed; (2) the TWO side streams and four
+ * events (fork, two joins, shadow rebuild) of pg_defer_weight_grads, created on first use; (3) up to
+ * 2 x 512 HIP event pairs while pg_profile_enable is on; (4) the switches set by pg_persist_disable /
+ * pg_defer_weight_grads / pg_profile_enable / pg_persist_spin_limit / pg_entry_checks (PG_NO_PERSIST is
+ * read once at first use) - process-global and NOT thread-safe: the Python layer toggles
+ * pg_defer_weight_grads around every training step, so two threads must not drive one process's
+ * library at once; (5) the 2-KiB static device array of pg_clip_adam_static; (6) a 64-entry host table
+ * "layout of the saved activations per workspace" (pg_decoder_fwd -> pg_decoder_bwd).  Nothing else
+ * persists between calls.
  *
  * Parameters are ONE flat fp32 buffer in the order of model.vae.parameters()
  * (vae_model.py:101-115, = optimiser order vae_trainer.py:99-100):
@@ -121,7 +125,9 @@ PG_API int pg_clip_adam_static(long n, float* params, const float* grads, float*
                                float lr, float beta1, float beta2, float eps, float max_norm, float* gnorm, void* stream);
 
 /* VAE.sample (vae_model.py:300-358): max_len-1 fused decode steps (3 GRU cells + vocab projection +
- * softmax(y/temp) + inverse-CDF draw or argmax + eos bookkeeping), no early exit, as the reference.
+ * softmax(y/temp) + inverse-CDF draw or argmax + eos bookkeeping).  The reference decodes every row to max_len and
+ * discards what follows a row's eos (vae_model.py:342-351); here a row LEAVES the decode at its eos (same tokens: its
+ * later draws are never recorded; PG_SAMPLE_NO_COMPACT=1 runs every row to max_len, the round-1 behaviour).
  * uniforms [max_len-1, n] (device) feed the draw of step i at uniforms[(i-1)*n + row]; NULL: Philox
  * keyed by (seed, row_offset + row, step).  tokens uint8 [n,max_len], end_pads int32 [n].
  * bf16, default decoder (Hd 512, 3 layers), a device with >= 256 CUs: the whole loop runs as ONE
@@ -155,7 +161,8 @@ PG_API int pg_dropout_masks_host(uint64_t seed, float p_drop, int n_masks, int B
 /* Kernel-level test hooks (no reference counterpart; they expose the MFMA tile engines that every
  * entry point above is built from, so tests can check them in isolation).
  * pg_gemm_nt: C[M,N] = alpha * A[M,K] . B[N,K]^T (+bias[N]) (+C32 if accumulate) -> C32 (fp32) and/or Ct (dtype).
- * pg_gemm_tn: C[M,N] += alpha * A[R,M]^T . B[R,N]  (fp32 atomics into C). */
+ * pg_gemm_tn: C[M,N] += alpha * A[R,M]^T . B[R,N]  (split over R across workgroups; this entry point, which lends no slab
+ * buffer, combines the splits with fp32 atomics into C; pg_gemm_tn_ws below can use slabs + a reduce kernel). */
 PG_API int pg_gemm_nt(int dtype, const void* A, long lda, const void* B, long ldb, int M, int N, int K, const float* bias,
                       float* C32, void* Ct, long ldc, int accumulate, float alpha, void* stream);
 PG_API int pg_gemm_tn(int dtype, const void* A, long lda, const void* B, long ldb, int M, int N, int R, float* C, long ldc,
@@ -183,8 +190,9 @@ PG_API int pg_profile_enable(int on);
 PG_API int pg_profile_read(int which, double* total_ms, long* launches, double* flop, int* segments);
 
 /* Deferred weight gradients (no reference counterpart; off by default).  While on, pg_decoder_bwd enqueues the decoder's
- * large weight-gradient GEMMs on a library-owned side stream (created on first use, never destroyed) so that they run
- * beside the following pg_encoder_bwd, a latency-bound kernel on a quarter of the CUs.  The decoder weight gradients are
+ * large weight-gradient GEMMs, alternating, on TWO library-owned side streams (created on first use, never destroyed; the
+ * second also takes the small embedding / z-projection / decoder_lat gradients) so that they run beside the dz chain and
+ * the following pg_encoder_bwd, a latency-bound kernel on a quarter of the CUs.  The decoder weight gradients are
  * complete, in the order of the caller's stream, after the next pg_encoder_bwd or pg_clip_adam on that stream, or after
  * pg_deferred_join(stream) (e.g. the stream a gradient all-reduce will run on).  A caller that reads the gradients
  * without any of the three must leave this off.  pg_defer_weight_grads returns the previous setting (on < 0: query). */
@@ -201,6 +209,17 @@ PG_API int pg_deferred_join(void* stream);
  * returns the previous one (limit < 0: query; 0 makes every unsatisfied wait give up at once - the test hook). */
 PG_API int pg_check_failure(void* stream);
 PG_API unsigned pg_persist_spin_limit(long limit);
+/* Data parallelism (no reference counterpart): the give-up word is per process, while a failing rank's gradients have
+ * already been summed into every rank.  pg_fail_flag_export copies the device word to dst[0] (device memory) behind the
+ * work queued on `stream`; the caller MAX-all-reduces that int over the ranks and pg_fail_flag_import writes the result
+ * back (and refreshes the pinned mirror) BEFORE pg_clip_adam, so that EVERY rank skips the update and EVERY rank's next
+ * pg_check_failure returns PG_ERR_PERSIST. */
+PG_API int pg_fail_flag_export(int32_t* dst, void* stream);
+PG_API int pg_fail_flag_import(const int32_t* src, void* stream);
+/* pg_entry_checks(0): the entry points stop polling the mirror on entry (a rank that raised in the middle of a step
+ * would leave its peers in the step's all-reduce); pg_check_failure still reports.  The data-parallel trainer switches
+ * them off for an epoch and checks at its end, on every rank.  Returns the previous setting (on < 0: query). */
+PG_API int pg_entry_checks(int on);
 
 /* Test / A-B hook (no reference counterpart): the recurrences run as persistent kernels where the shape is covered
  * (bf16, Hq = 256, Hd = 512); mask bits force the per-step kernels instead: 1 encoder, 2 decoder forward, 4 decoder BPTT,

@@ -450,7 +450,9 @@ static int launch_gemm_tn_cfg(const T* A, long lda, const T* B, long ldb, int M,
   // two-stage reduction when the caller lent a slab buffer that holds every split's tiles and the output is large enough
   // for the atomics to matter (the column sums stay atomic: a few KB)
   const size_t need = (size_t)splits * tiles * Cfg::BM * Cfg::BN * sizeof(float);
-  const bool two_stage = partial && need <= partial_bytes && splits >= 4 && tiles >= 16;
+  // (with a device-side scale the fused column sums are accumulated inside the GEMM kernel, which on the two-stage path
+  // no longer sees alpha_dev: that combination takes the atomic path instead of producing unscaled bias gradients)
+  const bool two_stage = partial && need <= partial_bytes && splits >= 4 && tiles >= 16 && !(alpha_dev && (colsum_a || colsum_b));
   PG_LAUNCH_BIG_SMEM(gemm_tn_kernel<Cfg>, grid, dim3(Cfg::NTHREADS), Cfg::SMEM_BYTES, stream, A, lda, B, ldb, M, N, R,
                      rows_per_split, splits, C, ldc, alpha, two_stage ? nullptr : alpha_dev, colsum_a, colsum_b,
                      two_stage ? partial : (float*)nullptr);

@@ -193,6 +193,11 @@ template <int V> struct IC { static constexpr int value = V; };
 template <int H, bool TOP, int AUXL, bool DBG, bool FAST>
 __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched& sd, int g, int l, int c, char* smem) {
   using G = BwdGeo<H, TOP>;
+  // The knock-out switches (PG_PERSIST_DBG) must never meet the exact-count waits of the FAST path: bit 1 drops the
+  // LDS-DMA, and an `s_waitcnt vmcnt(24)` that assumes 24 younger transfers would then let the epilogue's own loads land
+  // in registers already reused (a GPU fault).  The DBG instantiations load the epilogue inputs from C++ (hipcc's own
+  // conservative waits) and skip wait_parts with the DMA; this assert keeps it that way.
+  static_assert(!(DBG && FAST), "the instrumented instantiation must not use the exact-count epilogue waits");
   const int dbg = DBG ? a.dbg : 0;
   constexpr int NCU = G::NCU, ROWW = G::ROWW, NSLOT = G::NSLOT, D = G::D;
   static_assert(H == 512, "one LDS-DMA instruction (64 lanes x 16 B) must cover exactly 512 gate columns of one row");

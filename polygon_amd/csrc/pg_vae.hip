@@ -203,7 +203,20 @@ static bool use_persistent(int H) { return !(persist_off_mask() & 1) && enc_pers
 // partially available).  Everything computed since that launch is suspect - the Adam kernel has skipped its updates on
 // seeing the device word - so THIS call fails, loudly, once; the library then clears the word and switches every
 // recurrence to the per-step kernels, which need no co-residency, so later calls work (pg_persist_disable(0) re-enables).
-int check_persist() {
+static int g_entry_checks = 1;
+static int check_persist_now();
+int check_persist() { return g_entry_checks ? check_persist_now() : PG_OK; }
+// Entry points poll the give-up word's mirror when they are called, i.e. whenever the device happens to have finished
+// the failing kernel: under data parallelism a rank that raised in the MIDDLE of a step would leave its peers waiting in
+// the step's all-reduce.  The data-parallel trainer therefore switches the entry checks off for the epoch and relies on
+// the shared flag (pg_fail_flag_export / _import: every rank skips the update) and on pg_check_failure at the epoch's end,
+// which every rank reaches.  Returns the previous setting (on < 0: query).
+extern "C" int pg_entry_checks(int on) {
+  const int old = g_entry_checks;
+  if (on >= 0) g_entry_checks = on ? 1 : 0;
+  return old;
+}
+static int check_persist_now() {
   if (persist_poll_failure() == 0) return PG_OK;
   PG_TRY(persist_recover());
   g_persist_off = 15;
@@ -214,7 +227,27 @@ int check_persist() {
 
 extern "C" int pg_check_failure(void* stream) {
   PG_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-  return check_persist();
+  return check_persist_now();
+}
+
+// Data parallelism: the give-up word is per process, but a rank whose recurrence gave up has already SUM-all-reduced its
+// garbage gradients into every other rank.  The trainer therefore exports the word behind the step's kernels, MAX-all-
+// reduces it with the gradients and imports the result BEFORE pg_clip_adam: every rank's Adam kernel then skips the update
+// (weights stay identical across ranks) and every rank's next pg_check_failure raises (nobody saves, nobody is left
+// waiting in a collective).
+extern "C" int pg_fail_flag_export(int32_t* dst, void* stream) {
+  PG_REQUIRE(dst, "pg_fail_flag_export: NULL buffer");
+  unsigned* dev = nullptr;
+  PG_TRY(persist_fail_words(&dev));
+  PG_CHECK_HIP(hipMemcpyAsync(dst, dev, sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return PG_OK;
+}
+extern "C" int pg_fail_flag_import(const int32_t* src, void* stream) {
+  PG_REQUIRE(src, "pg_fail_flag_import: NULL buffer");
+  unsigned* dev = nullptr;
+  PG_TRY(persist_fail_words(&dev));
+  PG_CHECK_HIP(hipMemcpyAsync(dev, src, sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return persist_fail_mirror((hipStream_t)stream);
 }
 
 // ---- deferred weight gradients: the decoder's large weight-gradient GEMMs run on a library-owned side stream, beside the
@@ -300,6 +333,26 @@ static bool sv_pairs_adjacent(const TrainWs& w, int L) {
 }
 static bool use_persistent_dec(int H, int L, int B) { return !(persist_off_mask() & 2) && dec_persist_supported(H, L, B); }
 static bool use_persistent_dec_bwd(int H, int L, int B) { return !(persist_off_mask() & 4) && dec_persist_supported(H, L, B); }
+
+// Layout of the saved gate activations r, z, n, hn in a training workspace: packed rows (0) or the persistent kernels'
+// lane order (1).  pg_decoder_fwd RECORDS what it wrote, per workspace, and pg_decoder_bwd reads the record instead of
+// deriving the layout again from the persist mask current at ITS call: the mask can change in between (a detected
+// give-up switches every recurrence to the per-step kernels; pg_persist_disable is an A/B hook), and a BPTT that reads
+// lane-ordered activations as packed rows produces silently wrong gradients.
+struct SvLayoutRec { const void* ws; int lane; };
+static SvLayoutRec g_sv_layout[64] = {};
+static int g_sv_layout_next = 0;
+static void sv_layout_record(const void* ws, int lane) {
+  for (auto& r : g_sv_layout)
+    if (r.ws == ws) { r.lane = lane; return; }
+  g_sv_layout[g_sv_layout_next] = SvLayoutRec{ws, lane};
+  g_sv_layout_next = (g_sv_layout_next + 1) % 64;
+}
+static int sv_layout_of(const void* ws) {   // -1: no forward pass with save_for_backward ran on this workspace
+  for (const auto& r : g_sv_layout)
+    if (r.ws == ws) return r.lane;
+  return -1;
+}
 
 template <typename T> static int convert_to(const float* in, T* out, long n, hipStream_t st) {
   hipLaunchKernelGGL(convert_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, st, in, out, n);
@@ -541,6 +594,7 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
         if (save) for (int i = 0; i < 5; ++i) pa.sv[l][i] = at<T>(ws, w.d_sv[l][i]);
       }
       pa.sv_lane = (use_persistent_dec_bwd(Hd, L, B) && sv_pairs_adjacent(w, L)) ? 1 : 0;   // the BPTT of this step will be the persistent kernel too
+      if (save) sv_layout_record(ws, pa.sv_lane);
       pa.table = at<float>(shadow, so.tab_dec); pa.tok = at<int>(ws, w.dec_tok); pa.zproj = at<float>(ws, w.d_zproj);
       pa.h0_op = at<T>(ws, w.d_h0_op); pa.h0_32 = at<float>(ws, w.d_h0_32);
       pa.p_drop = p_drop; pa.seed = seed; pa.b_mul = b_mul; pa.b_add = b_add;
@@ -553,6 +607,7 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
       persist = true;
     }
   }
+  if (!persist && save) sv_layout_record(ws, 0);
   const int pslot = persist ? -1 : prof_begin(0, st);
   double pflop = 0.0;
   for (int dgi = 0; dgi < sd.T + L - 1 && !persist; ++dgi) {
@@ -671,6 +726,13 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   // BPTT as a wavefront: cell (l, t) needs (l, t+1) and (l+1, t); the gradient coming down from layer l+1 is
   // computed inside the cell (dGI_{l+1,t} . W_ih_{l+1}, through layer l's dropout mask), so no per-layer dX GEMM.
   bool persist = false;
+  const int sv_lane = sv_layout_of(ws);
+  PG_REQUIRE(sv_lane >= 0, "pg_decoder_bwd: no pg_decoder_fwd(save_for_backward = 1) has run on this workspace");
+  // the forward pass wrote lane order expecting the persistent BPTT; the per-step BPTT cannot read it (after a give-up or
+  // a pg_persist_disable between the two calls the step has to restart from pg_decoder_fwd)
+  PG_REQUIRE(!(sv_lane == 1 && !(std::is_same<T, bf16_t>::value && use_persistent_dec_bwd(Hd, L, B))),
+             "pg_decoder_bwd: the forward pass saved its activations for the persistent BPTT kernel, which is now disabled "
+             "(PG_ERR_PERSIST or pg_persist_disable since pg_decoder_fwd): restart the step from pg_decoder_fwd");
   if constexpr (std::is_same<T, bf16_t>::value) {
     if (use_persistent_dec_bwd(Hd, L, B)) {   // ONE launch: W_hh^T / W_ih_up^T rows stationary per workgroup, layers pipelined top-down
       DecBwdPersist pa;
@@ -687,7 +749,7 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
       pa.p_drop = p_drop; pa.seed = seed; pa.b_mul = b_mul; pa.b_add = b_add;
       pa.sync = at<unsigned>(ws, w.sync);
       const int ps = prof_begin(1, st);
-      pa.sv_lane = (use_persistent_dec(Hd, L, B) && sv_pairs_adjacent(w, L)) ? 1 : 0;   // the forward pass of this step was the persistent kernel
+      pa.sv_lane = sv_lane;   // what the forward pass of this step recorded (not re-derived: the persist mask may have changed)
       PG_TRY(launch_dec_bwd_persist(pa, sd, Hd, dh0, at<T>(ws, w.b_dh0_op), st));
       double pf = 0.0;   // algorithmic flop: dh = dGH_{t+1}.W_hh (+ dGI_{l+1,t}.W_ih_{l+1} below the top layer)
       for (int t = -1; t < sd.T; ++t) {

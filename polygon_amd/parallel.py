@@ -49,6 +49,7 @@ class GradComm:
         self.group = group
         self.work = None
         self.stream = None
+        self._flag = None
         # gloo (CPU rehearsals, two ranks sharing one GPU in the tests) moves device tensors through host copies; the
         # deployment backend is nccl (= RCCL on ROCm), which reduces in place on the device
         self.staged = dist.get_backend(group) != "nccl"
@@ -79,9 +80,29 @@ class GradComm:
         with torch.cuda.stream(self.stream):
             self.work = dist.all_reduce(grads[dec_start:], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def _share_failure(self, dev):
+        """MAX over the ranks of the persistent kernels' give-up word (include/polygon_hip.h, pg_fail_flag_export): a
+        rank whose recurrence gave up has already summed garbage into every rank's gradients, so every rank's Adam kernel
+        must skip this update and every rank must raise at its next check.  Rides behind the encoder bucket."""
+        import ctypes
+        from polygon_amd import _lib
+        L = _lib.lib()
+        if self._flag is None or self._flag.device != dev:
+            self._flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(L.pg_fail_flag_export(_lib.ptr(self._flag), st), "pg_fail_flag_export")
+        if self.staged:
+            h = self._flag.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+            self._flag.copy_(h)
+        else:
+            dist.all_reduce(self._flag, op=dist.ReduceOp.MAX, group=self.group)
+        _lib.check(L.pg_fail_flag_import(_lib.ptr(self._flag), st), "pg_fail_flag_import")
+
     def finish(self, grads, dec_start):
         if grads.is_cuda and self.staged:
             self._staged_sum(grads[:dec_start])
+            self._share_failure(grads.device)
             return
         w2 = dist.all_reduce(grads[:dec_start], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if self.work is not None:
@@ -90,6 +111,8 @@ class GradComm:
                 torch.cuda.current_stream(grads.device).wait_stream(self.stream)
             self.work = None
         w2.wait()
+        if grads.is_cuda:
+            self._share_failure(grads.device)
 
     def sum_scalars(self, t):
         """In-place SUM all-reduce of a small tensor of per-rank partial losses (the kernels normalise by GLOBAL counts,

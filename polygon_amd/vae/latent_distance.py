@@ -21,7 +21,10 @@ def latent_distance_scores(model, smiles_list, z_targets, n_top=None, agg="mean"
         raise ValueError("agg must be mean, max or min (custom_scoring_fcn.py:173-178)")
     k = z_targets.shape[0] if n_top is None else int(n_top)
     mu = model.encode_smiles(list(smiles_list), batch_size=batch_size)          # [n, d_z]
-    d = torch.cdist(mu, z_targets.to(mu.device), p=2)                           # [n, n_targets]
+    # exact differences as the reference's torch.norm(z_targets - z, dim=1): cdist's default switches to the matmul
+    # formulation above 25 rows, which loses ~1e-3 absolute on near-identical vectors - the small distances this scorer
+    # rewards and ranks by
+    d = torch.cdist(mu, z_targets.to(mu.device), p=2, compute_mode="donot_use_mm_for_euclid_dist")   # [n, n_targets]
     d = d.sort(dim=1)[0][:, :k]
     r = d.mean(1) if agg == "mean" else d.max(1)[0] if agg == "max" else d.min(1)[0]
     return r.float().cpu().numpy()

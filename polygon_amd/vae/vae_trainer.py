@@ -244,6 +244,19 @@ class VAETrainer:
         debug = logging.getLogger().isEnabledFor(logging.DEBUG)
         pending = []          # device scalars read back once per epoch unless per-batch debug logging is on
         lr = 0.
+        # data parallel: no rank may raise in the middle of a step (its peers would wait in the all-reduce); a give-up is
+        # shared through the gradient reduction (GradComm._share_failure) and raised by every rank at the epoch's end
+        checks = _lib.lib().pg_entry_checks(0) if world > 1 else None
+        try:
+            return self._epoch_body(epoch, data_loader, kl_weight, optimizer, label, t_epoch, n_batches, kl_buf, rec_buf, loss_buf,
+                                    rank, world, fused, comm, eng, debug, pending, lr)
+        finally:
+            if checks is not None:
+                _lib.lib().pg_entry_checks(checks)
+
+    def _epoch_body(self, epoch, data_loader, kl_weight, optimizer, label, t_epoch, n_batches, kl_buf, rec_buf, loss_buf,
+                    rank, world, fused, comm, eng, debug, pending, lr):
+        model = self.model
         for i, batch in enumerate(self._prefetch(data_loader)):
             t_batch = time.process_time()
             if world > 1:
@@ -252,7 +265,7 @@ class VAETrainer:
                 if batch.global_rows < world:
                     continue   # a tail with fewer strings than ranks would leave some ranks without rows: skipped on EVERY rank
             if fused or world > 1:
-                eng.ensure_shadow()
+                eng.ensure_flat()      # (the shadow weights are rebuilt inside train_step / eval_losses, under deferral)
                 b = batch if isinstance(batch, TokenBatch) else None
                 if b is None:
                     from polygon_amd.vae.vae_model import _as_batch

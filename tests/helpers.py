@@ -39,7 +39,7 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
-def dropout_masks(seed, p_drop, n_masks, B, T, H, b_mul=1, b_add=0):
+def dropout_masks(seed, p_drop, n_masks, B, T, H, b_mul=1, b_add=0, dtype=np.float64):
     """The inter-layer dropout masks the HIP kernels apply (pg_dropout_masks_host: the kernels' own hash, evaluated on the
     host) as the list of [B,T,H] float64 arrays oracle.decoder_forward(drop_masks=...) takes."""
     import ctypes
@@ -47,4 +47,4 @@ def dropout_masks(seed, p_drop, n_masks, B, T, H, b_mul=1, b_add=0):
     out = np.empty((n_masks, B, T, H), dtype=np.float32)
     _lib.check(_lib.lib().pg_dropout_masks_host(ctypes.c_uint64(seed), ctypes.c_float(p_drop), n_masks, B, T, H, b_mul, b_add,
                                                 out.ctypes.data_as(ctypes.c_void_p)), "pg_dropout_masks_host")
-    return [out[l].astype(np.float64) for l in range(n_masks)]
+    return [out[l] if dtype == np.float32 else out[l].astype(dtype) for l in range(n_masks)]   # float32: views, no copies

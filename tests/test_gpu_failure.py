@@ -87,3 +87,46 @@ def test_trainer_raises_before_saving(tmp_path):
         L.pg_persist_spin_limit(ctypes.c_long(old))
         L.pg_persist_disable(0)
     assert not list(tmp_path.glob("*.pt")), "a checkpoint was written after a failed recurrence"
+
+
+def test_layout_of_saved_activations_is_recorded_not_rederived():
+    """The forward pass records, per workspace, whether it saved r/z/n/hn in lane order (for the persistent BPTT) or as
+    packed rows; pg_decoder_bwd reads that record.  Switching the persistent BPTT off BETWEEN the two calls (what a
+    detected give-up does) must fail loudly - the per-step BPTT cannot read lane order - and a step restarted from the
+    forward pass under the new mask must give the gradients of an undisturbed step."""
+    from polygon_amd.vae.vae_trainer import FusedClipAdam
+    L = _lib.lib()
+    model, _ = build_model(REAL, 5, "bf16", d_dropout=0.0)
+    model.train()
+    eng = model._engine
+    opt = FusedClipAdam(model, lr=0.0)
+    n = 96
+    batch = model.get_collate_fn()(list(O.synthetic_smiles(n, seed=4)))
+    eps = torch.from_numpy(np.random.default_rng(1).standard_normal((n, REAL["Dz"])).astype(np.float32)).cuda()
+    assert L.pg_persist_disable(-1) == 0
+    eng.train_step(batch, 0.5, opt.flat_grad, eps=eps)
+    ref = opt.flat_grad.clone()
+    ws = eng._ws
+    z, dz, scal = eng._small
+    # forward with the persistent kernels (lane-order saves), then the BPTT kernel is switched off
+    eng.encoder_fwd(ws, batch, eps, None, 1, z, None, None, scal[0:1])
+    eng.decoder_fwd(ws, batch, z, None, 0.0, 0, 0, 1, scal[1:2])
+    L.pg_persist_disable(4)
+    try:
+        with pytest.raises(_lib.PolygonHipError, match="restart the step from pg_decoder_fwd"):
+            eng.decoder_bwd(ws, batch, None, 0.0, 0, 0, 1.0, None, opt.flat_grad, dz)
+        # restarted from the forward pass under the new mask: packed rows + per-step BPTT
+        eng.train_step(batch, 0.5, opt.flat_grad, eps=eps)
+        err = ((opt.flat_grad - ref).abs().max() / ref.abs().max()).item()
+        assert err <= 5e-3, err
+        # and the other direction: packed rows saved under mask 4 are read as packed rows by the persistent BPTT
+        eng.encoder_fwd(ws, batch, eps, None, 1, z, None, None, scal[0:1])
+        eng.decoder_fwd(ws, batch, z, None, 0.0, 0, 0, 1, scal[1:2])
+    finally:
+        L.pg_persist_disable(0)
+    opt.flat_grad.zero_()
+    eng.decoder_bwd(ws, batch, None, 0.0, 0, 0, 1.0, None, opt.flat_grad, dz)
+    eng.encoder_bwd(ws, batch, None, dz, 0.5, None, opt.flat_grad)
+    torch.cuda.synchronize()
+    err = ((opt.flat_grad - ref).abs().max() / ref.abs().max()).item()
+    assert err <= 5e-3, err

@@ -1,12 +1,14 @@
-"""Size-independent properties at BASELINE.json's full sizes (where the numpy oracle would take minutes): the sampler at
-8192 rows (configs[3]/[4]), the fused training step at n_batch 1024 bf16 with dropout (configs[1]) and at n_batch 512
-fp32 (configs[0]).  Parity proper is pinned at oracle-sized inputs in the other GPU test files."""
+"""BASELINE.json's full sizes.  DIRECT oracle parity of one training step at configs[0] (n_batch 512, fp32) and configs[1]
+(n_batch 1024, bf16, d_dropout 0.2, the persistent kernels in their 10-group configuration; the numpy oracle takes a few
+seconds per step at these sizes), the sampler's > 65 536-row chunk loop against separate calls, and size-independent
+properties: the sampler at 8192 rows (configs[3]/[4]) and the fused training step at both sizes."""
+import ctypes
 import numpy as np
 import pytest
 import torch
 
 from oracle import vae_oracle as O
-from tests.helpers import REAL, build_model, rel_err
+from tests.helpers import REAL, build_model, dropout_masks, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -66,3 +68,79 @@ def test_train_step_full_batch_properties(dt, n, p_drop):
         kl, rec = eng.train_step(batch, 0.5, opt.flat_grad, eps=eps, p_drop=p_drop, seed=9)
         opt.step()
     assert rec.item() < first - 0.05, (first, rec.item())
+
+
+def _profile_read(which):
+    from polygon_amd import _lib
+    ms, n, fl, seg = ctypes.c_double(), ctypes.c_long(), ctypes.c_double(), ctypes.c_int()
+    _lib.check(_lib.lib().pg_profile_read(which, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), ctypes.byref(seg)))
+    return n.value, seg.value
+
+
+@pytest.mark.parametrize("dt,n,p_drop", [("fp32", 512, 0.0), ("fp32", 512, 0.2), ("bf16", 1024, 0.2)],
+                         ids=["configs0_fp32_512", "configs0_fp32_512_dropout", "configs1_bf16_1024_dropout"])
+def test_train_step_full_batch_matches_oracle(dt, n, p_drop):
+    """One training step at BASELINE's batch sizes against the numpy oracle directly (vae_model.py:151-166, 216-275 and
+    their autograd): kl / recon within 1e-3 (fp32) or 2e-2 (bf16), all 25 gradients within 1e-2.  With dropout the oracle
+    takes the kernels' own masks (pg_dropout_masks_host, float32 to bound memory).  The bf16 case must have run the
+    group-persistent recurrences (one launch each), which at 1024 rows means their 10-group / 240-workgroup layout."""
+    from polygon_amd import _lib
+    from polygon_amd.vae.vae_trainer import FusedClipAdam
+    seed = 20250310
+    model, P = build_model(REAL, 23, dt, d_dropout=p_drop)
+    model.train()
+    strings = list(O.synthetic_smiles(n, seed=n + 1))
+    batch = model.get_collate_fn()(list(strings))
+    eps = np.random.default_rng(11).standard_normal((n, REAL["Dz"])).astype(np.float32)
+    opt = FusedClipAdam(model, lr=0.0)
+    L = _lib.lib()
+    _lib.check(L.pg_profile_enable(1))
+    try:
+        _profile_read(0), _profile_read(1)
+        kl, rec = model._engine.train_step(batch, 0.5, opt.flat_grad, eps=torch.from_numpy(eps).cuda(), p_drop=p_drop, seed=seed)
+        torch.cuda.synchronize()
+        (nf, sf), (nb, sb) = _profile_read(0), _profile_read(1)
+    finally:
+        _lib.check(L.pg_profile_enable(0))
+    if dt == "bf16":
+        assert nf == sf == 1 and nb == sb == 1, ("persistent recurrences did not run", nf, sf, nb, sb)
+    else:
+        assert nf > 1 and nb > 1                                   # fp32: one launch per anti-diagonal
+    seqs = O.collate(strings)
+    T = max(len(s) for s in seqs)
+    dm = dropout_masks(seed, p_drop, REAL["L"] - 1, n, T, REAL["Hd"], dtype=np.float32) if p_drop > 0 else None
+    enc, dec = O.vae_forward(P, seqs, eps.astype(np.float64), dm)
+    G, _ = O.vae_backward(P, enc, dec, g_kl=0.5, g_recon=1.0)
+    tol = 1e-3 if dt == "fp32" else 2e-2
+    assert abs(kl.item() - enc["kl"]) <= tol * abs(enc["kl"]), (kl.item(), enc["kl"])
+    assert abs(rec.item() - dec["recon"]) <= tol * abs(dec["recon"]), (rec.item(), dec["recon"])
+    worst = 0.0
+    for name, g in zip(O.param_order(P), model._engine.grad_views(opt.flat_grad)):
+        e = rel_err(g, G[name])
+        worst = max(worst, e)
+        assert e <= 1e-2, (name, e)
+    print("n_batch %d %s p_drop %.1f: kl %.3e recon %.3e worst gradient %.2e" % (
+        n, dt, p_drop, abs(kl.item() - enc["kl"]) / abs(enc["kl"]), abs(rec.item() - dec["recon"]) / abs(dec["recon"]), worst))
+
+
+def test_sampler_chunk_loop_equals_separate_calls():
+    """n_batch above the 65 536 rows one library call takes: VAE.sample_tokens walks chunks (uniforms[:, r0:r0+m],
+    row_offset + r0; vae_model.py sample_tokens).  70 000 rows with pre-drawn uniforms must equal two separate calls on
+    the two row ranges, and - Philox mode - two calls that pass the chunks' row offsets."""
+    model, _ = build_model(REAL, 31, "bf16", eos_bias=1.0)
+    model.eval()
+    n, CH, max_len = 70000, 65536, 8
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(n, REAL["Dz"], generator=g).cuda()
+    u = torch.rand(max_len - 1, n, generator=g).cuda()
+    tok, ep = model.sample_tokens(n, max_len=max_len, z=z, uniforms=u)
+    a = model.sample_tokens(CH, max_len=max_len, z=z[:CH], uniforms=u[:, :CH].contiguous())
+    b = model.sample_tokens(n - CH, max_len=max_len, z=z[CH:], uniforms=u[:, CH:].contiguous(), row_offset=CH)
+    assert torch.equal(tok, torch.cat([a[0], b[0]])) and torch.equal(ep, torch.cat([a[1], b[1]]))
+    t = tok.cpu().numpy()
+    assert (t[:, 0] == model.bos).all() and len(np.unique(t[:, 1])) > 10          # rows really differ
+    tok2, ep2 = model.sample_tokens(n, max_len=max_len, z=z, seed=5, row_offset=100)
+    a = model.sample_tokens(CH, max_len=max_len, z=z[:CH], seed=5, row_offset=100)
+    b = model.sample_tokens(n - CH, max_len=max_len, z=z[CH:], seed=5, row_offset=100 + CH)
+    assert torch.equal(tok2, torch.cat([a[0], b[0]])) and torch.equal(ep2, torch.cat([a[1], b[1]]))
+    assert not torch.equal(tok2, tok)

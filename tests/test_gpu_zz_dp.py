@@ -107,6 +107,37 @@ assert both[0][0] == both[1][0] and len(mine) > 0, "ranks disagree on the genera
 assert abs(both[0][1] - both[1][1]) <= 2            # each rank scored about half of every payload
 assert os.path.exists(os.path.join(out, "GDM_2.pt")) == (rank == 0)
 print("rank", rank, "generate ok", flush=True)
+
+# a give-up on ONE rank: its gradients are garbage and have been summed into both ranks, so BOTH ranks must skip the
+# update (weights stay equal across ranks) and BOTH must raise at their next check (nobody saves, nobody hangs)
+import ctypes
+from polygon_amd import _lib
+L = _lib.lib()
+L.pg_persist_spin_limit.restype = ctypes.c_uint
+model, _ = build_model(REAL, 21, "bf16", device="cuda:0", d_dropout=0.0)
+model.train()
+eng = model._engine
+opt = FusedClipAdam(model, lr=1e-2)
+strings = O.synthetic_smiles(64, seed=6)
+sh = model.get_collate_fn(shard=(rank, world))(list(strings))
+eps = torch.from_numpy(np.random.default_rng(2).standard_normal((64, REAL["Dz"])).astype(np.float32)).cuda()[rank::world].contiguous()
+comm = GradComm()
+eng.train_step(sh, 0.4, opt.flat_grad, eps=eps, comm=comm); opt.step()
+assert L.pg_check_failure(_lib.stream_ptr()) == 0
+before = eng.flat.clone()
+old = L.pg_persist_spin_limit(ctypes.c_long(0)) if rank == 1 else None
+checks = L.pg_entry_checks(0)                 # as VAETrainer does under data parallelism: nobody raises mid-step
+try:
+    eng.train_step(sh, 0.4, opt.flat_grad, eps=eps, comm=comm); opt.step()
+    torch.cuda.synchronize()
+finally:
+    L.pg_entry_checks(checks)
+    if rank == 1:
+        L.pg_persist_spin_limit(ctypes.c_long(old))
+assert torch.equal(eng.flat, before), "rank %%d applied an update although a rank's recurrence gave up" %% rank
+assert L.pg_check_failure(_lib.stream_ptr()) == -5, "rank %%d did not see the other rank's failure" %% rank
+L.pg_persist_disable(0)
+print("rank", rank, "shared failure ok", flush=True)
 dist.barrier(); dist.destroy_process_group()
 '''
 
