@@ -26,7 +26,9 @@ def test_decode_teacher_forced_matches_oracle(dt):
     if dt == "fp32":
         assert got == want
     else:       # bf16 logits may flip an argmax between two near-equal entries: nearly all rows identical
-        assert np.mean([a == b for a, b in zip(got, want)]) >= 0.9
+        same = np.mean([a == b for a, b in zip(got, want)])
+        print("bf16 teacher-forced decode: rows identical to the oracle %.3f" % same)
+        assert same >= 0.95                                    # measured 1.000 on the MI355X (42 rows)
     # decode(z) without x samples (vae_model.py:198-199): one string per row
     out = model.decode(torch.from_numpy(z[:5]).cuda())
     assert len(out) == 5 and all(isinstance(s, str) for s in out)

@@ -117,4 +117,4 @@ def test_bf16_sampler_teacher_forced_vs_oracle(golden_dir, mask, golden_bias):
     got = model.vocabulary.decode_batch(free_tok.cpu().numpy(), free_ep.cpu().numpy())
     same = np.mean([a == b for a, b in zip(got, O.tokens_to_strings(x, ep))])
     print("bf16 free-running rows identical to the reference: %.3f (max prob err teacher-forced %.2e)" % (same, err))
-    assert same >= 0.5
+    assert same >= 0.95                                            # measured 1.000 (eos-biased head) / 0.984 (plain head: 1 of 64 rows)

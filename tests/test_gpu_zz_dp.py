@@ -125,7 +125,11 @@ comm = GradComm()
 eng.train_step(sh, 0.4, opt.flat_grad, eps=eps, comm=comm); opt.step()
 assert L.pg_check_failure(_lib.stream_ptr()) == 0
 before = eng.flat.clone()
+# (this test runs with PG_NO_PERSIST=14 because its ranks share one GPU; rank 1 alone switches its persistent decoder
+# kernels on for the failing step - they give up at their first unsatisfied wait, so residency does not matter)
 old = L.pg_persist_spin_limit(ctypes.c_long(0)) if rank == 1 else None
+if rank == 1:
+    L.pg_persist_disable(0)
 checks = L.pg_entry_checks(0)                 # as VAETrainer does under data parallelism: nobody raises mid-step
 try:
     eng.train_step(sh, 0.4, opt.flat_grad, eps=eps, comm=comm); opt.step()
