@@ -181,6 +181,9 @@ int launch_dec_sample_persist(DecSamplePersist& a, hipStream_t stream);
 int persist_off_mask();
 
 bool dec_persist_supported(int H, int L, int B);
+// the two-waves-per-SIMD forward kernel of the training configuration (pg_persist_dec8.hip), launched by launch_dec_fwd_persist
+bool dec_fwd8_enabled();
+int launch_dec_fwd8(DecFwdPersist& a, const Sched& sd, int grid, hipStream_t stream);
 int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t stream);
 // runs the whole decoder BPTT recurrence, then dh0_32 / dh0_op [B, H] = sum over layers of the h0 gradients
 int launch_dec_bwd_persist(DecBwdPersist& a, const Sched& sd, int H, float* dh0_32, bf16_t* dh0_op, hipStream_t stream);

@@ -190,7 +190,10 @@ template <int V> struct IC { static constexpr int value = V; };
 // lane order) known at compile time.  The step body is compiled three times - first step (no recurrent operand), steady
 // state, last step (t = -1, the gradient of h0) - so that the tile loop has no block-uniform branches left: one wave per
 // SIMD pays for every scalar branch with idle matrix pipes.
-template <int H, bool TOP, int AUXL, bool DBG, bool FAST>
+// SVL (FAST only): lane order of the saved activations - 1: (r, z) / (n, hn) pairs as the 4-wave forward kernel writes
+// them, 2: the pair-split order of the two-waves-per-SIMD forward kernel (pg_persist_dec8.hip: {r, z, n, hn} of units 0-1 in
+// the first region, of units 2-3 in the second).  The other instantiations read a.sv_lane at run time.
+template <int H, bool TOP, int AUXL, bool DBG, bool FAST, int SVL>
 __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched& sd, int g, int l, int c, char* smem) {
   using G = BwdGeo<H, TOP>;
   // The knock-out switches (PG_PERSIST_DBG) must never meet the exact-count waits of the FAST path: bit 1 drops the
@@ -237,6 +240,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
   const float inv_keep = a.p_drop > 0.0f ? 1.0f / (1.0f - a.p_drop) : 1.0f;
   const bool drop = FAST ? !TOP : (!TOP && a.p_drop > 0.0f);
   const bool sv_lane = FAST ? true : a.sv_lane != 0;
+  const bool sv_split = FAST ? SVL == 2 : a.sv_lane == 2;
   bf16_t* dGI = a.dGI[l];
   bf16_t* dGH = a.dGH[l];
   const bf16_t* dGIup = TOP ? nullptr : a.dGI[l + 1];
@@ -388,10 +392,17 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
             const long sl = ((sv_tile_slot(o, t, NG, j, g) * NCU + c) * 256 + wave * 64 + lane) * 8;
             const u32x4 prz = *reinterpret_cast<const u32x4*>(a.sv[l][0] + sl);
             const u32x4 pnh = *reinterpret_cast<const u32x4*>(a.sv[l][2] + sl);
-            svr = __builtin_bit_cast(bf16x4, u32x2{prz[0], prz[1]});
-            svz = __builtin_bit_cast(bf16x4, u32x2{prz[2], prz[3]});
-            svn = __builtin_bit_cast(bf16x4, u32x2{pnh[0], pnh[1]});
-            svhn = __builtin_bit_cast(bf16x4, u32x2{pnh[2], pnh[3]});
+            if (sv_split) {   // kernel-uniform
+              svr = __builtin_bit_cast(bf16x4, u32x2{prz[0], pnh[0]});
+              svz = __builtin_bit_cast(bf16x4, u32x2{prz[1], pnh[1]});
+              svn = __builtin_bit_cast(bf16x4, u32x2{prz[2], pnh[2]});
+              svhn = __builtin_bit_cast(bf16x4, u32x2{prz[3], pnh[3]});
+            } else {
+              svr = __builtin_bit_cast(bf16x4, u32x2{prz[0], prz[1]});
+              svz = __builtin_bit_cast(bf16x4, u32x2{prz[2], prz[3]});
+              svn = __builtin_bit_cast(bf16x4, u32x2{pnh[0], pnh[1]});
+              svhn = __builtin_bit_cast(bf16x4, u32x2{pnh[2], pnh[3]});
+            }
           } else {
             svr = *reinterpret_cast<const bf16x4*>(a.sv[l][0] + sidx);
             svz = *reinterpret_cast<const bf16x4*>(a.sv[l][1] + sidx);
@@ -505,10 +516,17 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
         epi_wait<Pt>(j * Pt + Pt + AHEAD <= nparts, q_cr, q_top, q_rz, q_nh, q_hp);
         cr = __builtin_bit_cast(f32x4, q_cr);
         dtop = __builtin_bit_cast(f32x4, q_top);
-        svr = __builtin_bit_cast(bf16x4, u32x2{q_rz[0], q_rz[1]});
-        svz = __builtin_bit_cast(bf16x4, u32x2{q_rz[2], q_rz[3]});
-        svn = __builtin_bit_cast(bf16x4, u32x2{q_nh[0], q_nh[1]});
-        svhn = __builtin_bit_cast(bf16x4, u32x2{q_nh[2], q_nh[3]});
+        if constexpr (SVL == 2) {
+          svr = __builtin_bit_cast(bf16x4, u32x2{q_rz[0], q_nh[0]});
+          svz = __builtin_bit_cast(bf16x4, u32x2{q_rz[1], q_nh[1]});
+          svn = __builtin_bit_cast(bf16x4, u32x2{q_rz[2], q_nh[2]});
+          svhn = __builtin_bit_cast(bf16x4, u32x2{q_rz[3], q_nh[3]});
+        } else {
+          svr = __builtin_bit_cast(bf16x4, u32x2{q_rz[0], q_rz[1]});
+          svz = __builtin_bit_cast(bf16x4, u32x2{q_rz[2], q_rz[3]});
+          svn = __builtin_bit_cast(bf16x4, u32x2{q_nh[0], q_nh[1]});
+          svhn = __builtin_bit_cast(bf16x4, u32x2{q_nh[2], q_nh[3]});
+        }
         svhp = __builtin_bit_cast(bf16x4, q_hp);
       }
       // ---- epilogue on 4 units of sequence b
@@ -613,15 +631,15 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
   }
 }
 
-template <int H, int AUXL, bool DBG, bool FAST>
+template <int H, int AUXL, bool DBG, bool FAST, int SVL = 1>
 __global__ __launch_bounds__(256) void dec_bwd_persist_kernel(DecBwdPersist a, Sched sd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NCU = H / 64;
   int g, li, c;   // blockIdx % 8 labels the XCD: a group's workgroups (or at least a layer's) share one
   if (!persist_map(blockIdx.x, a.NG, NCU, g, li, c)) return;
   const int l = a.L - 1 - li;                               // top layer first: it is the head of the dependency chain
-  if (l == a.L - 1) dec_bwd_body<H, true, AUXL, DBG, FAST>(a, sd, g, l, c, smem);
-  else dec_bwd_body<H, false, AUXL, DBG, FAST>(a, sd, g, l, c, smem);
+  if (l == a.L - 1) dec_bwd_body<H, true, AUXL, DBG, FAST, SVL>(a, sd, g, l, c, smem);
+  else dec_bwd_body<H, false, AUXL, DBG, FAST, SVL>(a, sd, g, l, c, smem);
 }
 
 // dh0 = sum over layers of the per-layer h0 gradients (every layer starts from the same decoder_lat(z))
@@ -658,13 +676,14 @@ int launch_dec_bwd_persist(DecBwdPersist& a, const Sched& sd, int H, float* dh0_
   const bool dbgk = a.dbg != 0 || a.stamps != nullptr;
   const bool plain = persist_dma_plain();
   const bool fast = !dbgk && !plain && a.L >= 2 && a.sv_lane && a.p_drop > 0.0f && !getenv("PG_PERSIST_NO_FAST");
-  const void* kern = fast    ? reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, AUX_SC1, false, true>)
+  const void* kern = fast    ? (a.sv_lane == 2 ? reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, AUX_SC1, false, true, 2>)
+                                                : reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, AUX_SC1, false, true, 1>))
                      : plain ? (dbgk ? reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, 0, true, false>)
                                      : reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, 0, false, false>))
                              : (dbgk ? reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, AUX_SC1, true, false>)
                                      : reinterpret_cast<const void*>(dec_bwd_persist_kernel<512, AUX_SC1, false, false>));
-  static bool attr_done[5] = {false, false, false, false, false};
-  const int ki = fast ? 4 : plain * 2 + dbgk;
+  static bool attr_done[6] = {false, false, false, false, false, false};
+  const int ki = fast ? (a.sv_lane == 2 ? 5 : 4) : plain * 2 + dbgk;
   if (!attr_done[ki]) {
     PG_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_done[ki] = true;

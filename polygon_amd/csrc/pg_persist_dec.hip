@@ -517,10 +517,28 @@ int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t
   a.stamps = g_stamps_which == 0 ? g_stamps : nullptr;
   a.dbg = getenv("PG_PERSIST_DBG") ? atoi(getenv("PG_PERSIST_DBG")) : 0;
   PG_CHECK_HIP(hipMemsetAsync(a.sync, 0, PG_PERSIST_SYNC_WORDS * sizeof(unsigned), stream));
-  const bool dbgk = a.dbg != 0 || a.stamps != nullptr;
+  // (PG_FWD8_KO=32, diagnostic builds only: the stamps go to the two-waves-per-SIMD kernel's own instrumented instantiation)
+  static const bool stamps8 = getenv("PG_FWD8_KO") && atoi(getenv("PG_FWD8_KO")) == 32;
+  const bool dbgk = a.dbg != 0 || (a.stamps != nullptr && !stamps8);
   const bool plain = persist_dma_plain();
   bool fast = !dbgk && !plain && a.L >= 2 && a.sv_lane && !getenv("PG_PERSIST_NO_FAST");      // the training configuration (see dec_fwd_body)
   for (int l = 0; l < a.L; ++l) fast = fast && a.sv[l][0] && ((a.hdrop[l] != nullptr) == (l < a.L - 1));
+  // Every workgroup waits for its peers, so the whole grid must be co-resident: one workgroup per CU (512 registers per
+  // lane, 130-145 KB LDS) on a device with at least `grid` CUs.  Checked here; a plain launch has the same residency as a
+  // cooperative one and works when several processes use the GPU (their kernels drain independently, waits are bounded).
+  const int grid = a.NG == 8 ? 8 * a.L * G::NCU : 256;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    PG_CHECK_HIP(hipGetDevice(&dev));
+    PG_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  PG_REQUIRE(grid <= n_cu, "dec_fwd_persist: %d workgroups cannot be co-resident on %d CUs", grid, n_cu);
+  if (fast && dec_fwd8_enabled()) {   // the training configuration: two waves per SIMD (pg_persist_dec8.hip)
+    PG_TRY(launch_dec_fwd8(a, sd, grid, stream));
+    PG_TRY(persist_fail_mirror(stream));
+    return PG_OK;
+  }
   const void* kern = fast    ? reinterpret_cast<const void*>(dec_fwd_persist_kernel<512, AUX_SC1, false, true>)
                      : plain ? (dbgk ? reinterpret_cast<const void*>(dec_fwd_persist_kernel<512, 0, true, false>)
                                      : reinterpret_cast<const void*>(dec_fwd_persist_kernel<512, 0, false, false>))
@@ -532,17 +550,6 @@ int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t
     PG_CHECK_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM));
     attr_done[ki] = true;
   }
-  // Every workgroup waits for its peers, so the whole grid must be co-resident: one workgroup per CU (512 registers per
-  // lane, 130 KB LDS) on a device with at least `grid` CUs.  Checked here; a plain launch has the same residency as a
-  // cooperative one and works when several processes use the GPU (their kernels drain independently, waits are bounded).
-  const int grid = a.NG == 8 ? 8 * a.L * G::NCU : 256;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    PG_CHECK_HIP(hipGetDevice(&dev));
-    PG_CHECK_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  }
-  PG_REQUIRE(grid <= n_cu, "dec_fwd_persist: %d workgroups cannot be co-resident on %d CUs", grid, n_cu);
   void* kargs[] = {&a, const_cast<Sched*>(&sd)};
   PG_CHECK_HIP(hipLaunchKernel(kern, dim3(grid), dim3(256), kargs, (size_t)G::SMEM, stream));
   PG_CHECK_LAUNCH();

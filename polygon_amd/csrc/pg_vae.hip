@@ -594,13 +594,13 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
         if (save) for (int i = 0; i < 5; ++i) pa.sv[l][i] = at<T>(ws, w.d_sv[l][i]);
       }
       pa.sv_lane = (use_persistent_dec_bwd(Hd, L, B) && sv_pairs_adjacent(w, L)) ? 1 : 0;   // the BPTT of this step will be the persistent kernel too
-      if (save) sv_layout_record(ws, pa.sv_lane);
       pa.table = at<float>(shadow, so.tab_dec); pa.tok = at<int>(ws, w.dec_tok); pa.zproj = at<float>(ws, w.d_zproj);
       pa.h0_op = at<T>(ws, w.d_h0_op); pa.h0_32 = at<float>(ws, w.d_h0_32);
       pa.p_drop = p_drop; pa.seed = seed; pa.b_mul = b_mul; pa.b_add = b_add;
       pa.sync = at<unsigned>(ws, w.sync);
       const int pslot = prof_begin(0, st);
       PG_TRY(launch_dec_fwd_persist(pa, sd, Hd, st));
+      if (save) sv_layout_record(ws, pa.sv_lane);   // what the launcher's kernel wrote: 1, or 2 (the two-waves-per-SIMD kernel's order)
       double pflop = 0.0;
       for (int t = 0; t < sd.T; ++t) pflop += 2.0 * sched_B(sd, t) * 3.0 * Hd * (L * Hd + (L - 1) * Hd);
       prof_end(0, pslot, st, 1, pflop);
@@ -730,7 +730,7 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   PG_REQUIRE(sv_lane >= 0, "pg_decoder_bwd: no pg_decoder_fwd(save_for_backward = 1) has run on this workspace");
   // the forward pass wrote lane order expecting the persistent BPTT; the per-step BPTT cannot read it (after a give-up or
   // a pg_persist_disable between the two calls the step has to restart from pg_decoder_fwd)
-  PG_REQUIRE(!(sv_lane == 1 && !(std::is_same<T, bf16_t>::value && use_persistent_dec_bwd(Hd, L, B))),
+  PG_REQUIRE(!(sv_lane >= 1 && !(std::is_same<T, bf16_t>::value && use_persistent_dec_bwd(Hd, L, B))),
              "pg_decoder_bwd: the forward pass saved its activations for the persistent BPTT kernel, which is now disabled "
              "(PG_ERR_PERSIST or pg_persist_disable since pg_decoder_fwd): restart the step from pg_decoder_fwd");
   if constexpr (std::is_same<T, bf16_t>::value) {

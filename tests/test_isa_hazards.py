@@ -12,7 +12,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-KERNELS = ["pg_persist_bwd.hip", "pg_persist_dec.hip", "pg_persist_sample.hip"]
+KERNELS = ["pg_persist_bwd.hip", "pg_persist_dec.hip", "pg_persist_dec8.hip", "pg_persist_sample.hip"]
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
