@@ -179,6 +179,14 @@ __device__ __forceinline__ void fwd8_wave(const DecFwdPersist& a, const Sched& s
         a.stamps[8 + (ROLE * 8 + i) * 8 + (slot)] = __builtin_amdgcn_s_memtime();                               \
     }                                                                                                           \
   } while (0)
+  // step-level stamps of the same pair, steps 20 .. 23: slots 0 .. 6 behind the tile stamps
+#define PG8_STEP_STAMP(slot)                                                                                    \
+  do {                                                                                                          \
+    if constexpr ((KO & 32) != 0) {                                                                             \
+      if (a.stamps && g == 0 && l == 1 && c == 0 && wave == 0 && t >= 20 && t < 24 && lane == 0)                \
+        a.stamps[8 + 128 + (ROLE * 4 + (t - 20)) * 8 + (slot)] = __builtin_amdgcn_s_memtime();                  \
+    }                                                                                                           \
+  } while (0)
   typedef __attribute__((address_space(3))) void* lptr_t;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) - 4 * ROLE;   // pair index 0..3
@@ -242,6 +250,7 @@ __device__ __forceinline__ void fwd8_wave(const DecFwdPersist& a, const Sched& s
   __syncthreads();
 
   for (int t = 0; t < Tg; ++t) {
+    PG8_STEP_STAMP(0);
     if constexpr (HS) {
       if (tid == 0) {
         bool ok = wait_ge8(cnt_own, (unsigned)(NCU * t), err, a.fail, a.spin_limit);
@@ -259,6 +268,7 @@ __device__ __forceinline__ void fwd8_wave(const DecFwdPersist& a, const Sched& s
     }
     __syncthreads();                                                               // Bar S
     if (*sFlag == 0u) return;
+    PG8_STEP_STAMP(1);
     const bf16_t* hprev_base = t == 0 ? a.h0_op : hseq + (long)op * H;
     const bf16_t* x_base = L0 ? hprev_base : xsrc + (long)o * H;
     const float* carry_src = (t == 0 ? a.h0_32 : carry) + c * 64;
@@ -466,6 +476,7 @@ __device__ __forceinline__ void fwd8_wave(const DecFwdPersist& a, const Sched& s
     }
     __builtin_amdgcn_s_barrier();                                                  // Bar P: tile 0 has landed
     asm volatile("" ::: "memory");
+    PG8_STEP_STAMP(2);
     for (int i = 0; i < ntile; ++i) {
       PG8_STAMP(0);
       if constexpr (HS) {
@@ -497,16 +508,20 @@ __device__ __forceinline__ void fwd8_wave(const DecFwdPersist& a, const Sched& s
       __builtin_amdgcn_s_barrier();                                                // Bar(i)
       asm volatile("" ::: "memory");
     }
+    PG8_STEP_STAMP(3);
     epilogue(ntile - 1);
     if (ntile >= 2) { row_stores(ntile - 2); relay_stores(ntile - 2); }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                                  // Bar E1: the last tile's rows are staged
     asm volatile("" ::: "memory");
+    PG8_STEP_STAMP(4);
     row_stores(ntile - 1);
     relay_stores(ntile - 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              // this step's stores have all been acknowledged
+    PG8_STEP_STAMP(5);
     __builtin_amdgcn_s_barrier();                                                  // Bar E2, then lane 0 publishes the step
     asm volatile("" ::: "memory");
+    PG8_STEP_STAMP(6);
     if constexpr (HS) {
       if (tid == 0) __hip_atomic_fetch_add(cnt_own, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

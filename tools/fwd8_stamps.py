@@ -14,7 +14,7 @@ eng = model._engine
 eng.ensure_shadow()
 gb = model.get_collate_fn()(synthetic_smiles(1024, seed=1))
 eps = torch.randn(1024, model.d_z, device="cuda")
-stamps = torch.zeros(8 + 128, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(8 + 128 + 64, dtype=torch.int64, device="cuda")
 L = _lib.lib()
 for i in range(3):
     eng.train_step(gb, 0.5, opt.flat_grad, eps=eps, p_drop=0.2, seed=i)
@@ -23,7 +23,9 @@ _lib.check(L.pg_persist_stamps(_lib.ptr(stamps), 0))
 eng.train_step(gb, 0.5, opt.flat_grad, eps=eps, p_drop=0.2, seed=7)
 torch.cuda.synchronize()
 _lib.check(L.pg_persist_stamps(None, 0))
-s = stamps.cpu().numpy()[8:].reshape(2, 8, 8)
+raw = stamps.cpu().numpy()
+s = raw[8:8 + 128].reshape(2, 8, 8)
+st = raw[8 + 128:].reshape(2, 4, 8)
 t0 = s[0, 0, 0]
 names = [["start", "dma issued", "epilogue", "mfma", "waited"], ["start", "stores", "mfma", "epilogue", "ready"]]
 for role in range(2):
@@ -32,3 +34,8 @@ for role in range(2):
         if s[role, i, 0] == 0:
             continue
         print("  tile %d: " % i + "  ".join("%s %d" % (names[role][k], s[role, i, k] - t0) for k in range(5)))
+snames = ["step begin", "polled+BarS", "tile0 landed", "loop done", "E1", "stores drained", "E2"]
+for role in range(2):
+    print("role %d step-level (cycles since step 20 began on the h side):" % role)
+    for k in range(4):
+        print("  step %d: " % (20 + k) + "  ".join("%s %d" % (snames[j], st[role, k, j] - st[0, 0, 0]) for j in range(7)))
