@@ -152,7 +152,7 @@ def profile_read(which):
 def pmc_traffic(kernel, dtype):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r0N_pmc_traffic.json, newest
     round first; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE); None when not measured."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % rnd)) as f:
                 t = json.load(f)
@@ -180,17 +180,33 @@ def roofline_recurrence(dtype):
     what = {"dec_bwd_persist_kernel": " (whole decoder BPTT in one group-persistent launch: 3 layers x T steps, weights "
                                       "stationary in registers + LDS, activations all-gathered per step by LDS-DMA)",
             "gru_bwd2_diag_kernel": " (one BPTT anti-diagonal per launch)"}[k_b]
+    traffic = pmc_traffic(k_b, dtype)
+    sec = ms_b / n_b * 1e-3
+    # the all-gather of the persistent kernel: every workgroup pulls its group's 3H-wide gate-gradient rows out of L2
+    # (96 KB per 16-row tile below the top layer, 48 KB in the top layer: DESIGN.md 3); per-step kernels: not modelled
+    l2_bytes = None
+    if k_b == "dec_bwd_persist_kernel":
+        operand_rows = fl_b / n_b / (2.0 * 3 * 512 * 512)          # gate-gradient rows consumed, summed over the cells
+        l2_bytes = operand_rows * (3 * 512 * 2) * 8                # each is 3H bf16 wide and read by the layer's 8 unit slices
     return {"bound": "mfma", "kernel": k_b + what,
             "achieved": ach, "peak": PEAK[dtype], "unit": "TFLOP/s", "frac": ach / PEAK[dtype],
-            "traffic": pmc_traffic(k_b, dtype),
+            "traffic": traffic,
+            "frac_hbm": None if traffic is None else traffic / sec / 8.0e12,
+            "l2_to_cu_bytes": l2_bytes, "frac_l2": None if l2_bytes is None else l2_bytes / sec / 34.5e12,
+            "bound_in_practice": "neither MFMA nor HBM nor L2 bandwidth: the per-step hand-off between workgroups (~3 us x T steps) and "
+                                 "the un-overlapped chain DMA landing -> MFMAs -> gate epilogue -> stores inside a tile; `frac` is "
+                                 "the MFMA fraction the contract asks for, frac_hbm / frac_l2 the memory-side ones",
             "avg_launch_us": ms_b / n_b * 1e3, "launches": n_b, "segments": seg_b, "flop_per_launch": fl_b / n_b,
-            "fwd_recurrence": {"kernel": k_f, "avg_launch_us": ms_f / n_f * 1e3, "launches": n_f,
+            "fwd_recurrence": {"kernel": k_f + (" (two waves per SIMD: dec_fwd8_persist_kernel)" if k_f == "dec_fwd_persist_kernel" and
+                                                not os.environ.get("PG_FWD8_OFF") else ""),
+                               "avg_launch_us": ms_f / n_f * 1e3, "launches": n_f,
                                "flop_per_launch": fl_f / n_f, "achieved": fl_f / (ms_f * 1e-3) / 1e12,
-                               "traffic": pmc_traffic(k_f, dtype)},
+                               "traffic": pmc_traffic("dec_fwd8_persist_kernel", dtype) or pmc_traffic(k_f, dtype)},
             "note": "the recurrence is a chain of T dependent steps of ~1-5 GFLOP each; inside the persistent launch a step is "
-                    "~1.5 us of inter-workgroup hand-off plus ~3 us per 16-row tile - the tile's all-gathered activations (96 KB per "
-                    "workgroup out of L2, 8 GB per launch), its 96 MFMAs per wave, its gate epilogue and stores run as a chain "
-                    "that the 4-slot LDS ring cannot overlap with the next tile - not MFMA throughput: DESIGN.md 3, 7"}
+                    "~3 us of inter-workgroup hand-off (poll, first tile's DMA, last tile's epilogue, store drain) plus ~3.3 us per "
+                    "16-row BPTT tile whose 96 MFMAs per wave are 0.64 us of matrix pipe (16 cycles per v_mfma_f32_16x16x32_bf16, "
+                    "tools/mfma_rate.hip) - the rest is DMA landing, LDS fragment latency, gate epilogue and stores on one wave "
+                    "per SIMD: DESIGN.md 3, 7"}
 
 
 # ---- CPU baseline (SURVEY.md 8d protocol) ------------------------------------------------------------------------
