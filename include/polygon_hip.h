@@ -49,11 +49,17 @@ extern "C" {
 #define PG_BF16 1 /* bf16 operands on v_mfma_f32_32x32x16_bf16, f32 accumulate, f32 state */
 #define PG_MAX_LAYERS 8
 #define PG_MAX_T 511  /* longest sequence (bos..eos) the packed scheduler accepts */
+#define PG_MAX_ENC_LAYERS 4 /* q_n_layers limit of the generic encoder */
 #define PG_MAX_V 64   /* vocabulary limit of the softmax / cross-entropy / draw kernels */
 
 typedef struct pg_dims {
   int V, E, Hq, Dz, Hd, L; /* vocab, embedding dim, encoder hidden, latent, decoder hidden, decoder layers */
   int pad, bos, eos, unk;
+  /* encoder shape (vae_model.py:63-81: q_n_layers, q_bidir).  0 / 0 = the reference's defaults (one layer, one
+   * direction), so a zero-initialised tail keeps its meaning.  Any other shape changes the flat parameter layout
+   * (pg_param_count: nn.GRU's order weight_ih, weight_hh, bias_ih, bias_hh per layer and direction, q_mu / q_logvar
+   * weights Dz x Hq*dirs) and is served by pg_encoder_gen_fwd / pg_encoder_gen_bwd; pg_encoder_fwd / _bwd refuse it. */
+  int Lq, qbidir;
 } pg_dims;
 
 /* data-parallel context of one call: rank r of G holds rows r, r+G, ... of the
@@ -107,6 +113,26 @@ PG_API int pg_decoder_bwd(const pg_dims* d, int dtype, const float* params, cons
 PG_API int pg_encoder_bwd(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes,
                           int B, int Tmax, const int32_t* h_lengths, const pg_dp* dp, const float* dz, float g_host,
                           const float* g_dev, float* grads, void* stream);
+
+/* VAE.forward_encoder for ANY encoder shape of vae_model.py:63-81 (pg_dims.Lq layers, pg_dims.qbidir directions) and its
+ * BPTT: nn.GRU(num_layers=q_n_layers, bidirectional=q_bidir, dropout=q_dropout) over the packed batch, the last layer's
+ * final state(s) concatenated forward|reverse (vae_model.py:228-229) into q_mu / q_logvar, reparameterisation and KL as
+ * pg_encoder_fwd.  Runs on the per-step GRU kernels (one launch per step, layer and direction; the reverse direction
+ * walks t = T-1 .. 0 and starts each sequence at its own last token, which is what a packed bidirectional GRU does) and
+ * the batched GEMM kernels for the input projections; it keeps its own operand copies of the encoder weights in ITS
+ * workspace (pg_encoder_gen_workspace_bytes, separate from the training workspace), rebuilt by every forward call, so it
+ * reads nothing of the shadow buffer.  p_drop / seed: nn.GRU's inter-layer dropout (q_dropout, only when Lq > 1), the
+ * same counter hash as the decoder's (pg_dropout_masks_host with H = Hq*dirs gives the masks of layers 0 .. Lq-2).
+ * Same argument meaning, outputs and error behaviour as pg_encoder_fwd / pg_encoder_bwd otherwise; the default shape is
+ * accepted too (a slower path to the same numbers, used by the tests). */
+PG_API size_t pg_encoder_gen_workspace_bytes(const pg_dims* d, int dtype, int B, long n_tokens);
+PG_API int pg_encoder_gen_fwd(const pg_dims* d, int dtype, const float* params, void* ws, size_t ws_bytes, int B, int Tmax,
+                              const int32_t* d_tokens, const int32_t* h_lengths, const float* eps, const pg_dp* dp,
+                              float p_drop, uint64_t seed, int save_for_backward, float* z, float* mu, float* logvar,
+                              float* kl, void* stream);
+PG_API int pg_encoder_gen_bwd(const pg_dims* d, int dtype, const float* params, void* ws, size_t ws_bytes, int B, int Tmax,
+                              const int32_t* h_lengths, const pg_dp* dp, float p_drop, uint64_t seed, const float* dz,
+                              float g_host, const float* g_dev, float* grads, void* stream);
 
 /* clip_grad_norm_(params, max_norm) + Adam.step() (vae_trainer.py:136-138) over the flat buffers.
  * scratch: >= 4 KiB device floats.  step = 1-based Adam step count.  max_norm <= 0 disables the

@@ -46,7 +46,10 @@ def load_params(model, P):
 
 def build(ns, dims, seed):
     P = O.init_params(seed=seed, **dims)
-    model = ns.VAE(q_d_h=dims['Hq'], d_z=dims['Dz'], d_d_h=dims['Hd'], d_n_layers=dims['L'])
+    # q_dropout = 0 for the encoder shapes with more than one layer: torch's own dropout stream cannot be pinned from
+    # outside (the dropout path is pinned through pg_dropout_masks_host instead, as the decoder's)
+    model = ns.VAE(q_d_h=dims['Hq'], d_z=dims['Dz'], d_d_h=dims['Hd'], d_n_layers=dims['L'],
+                   q_n_layers=dims.get('Lq', 1), q_bidir=bool(dims.get('bidir', False)), q_dropout=0.0)
     load_params(model, P)
     return model, P
 
@@ -191,15 +194,29 @@ def sample_fixture(ns, tag, dims, n, seed, max_len=100, temp=1.0, eos_bias=0.0):
     print(tag, 'sample lens', [len(s) for s in strings][:8])
 
 
+TINY_STRINGS = ["CCl", "c1ccccc1Br", "C[nH]1cccc1", "N[C@@H](C)C(=O)O", "C", "CC(=O)Oc1ccccc1C(=O)O", "C#N", "OO",
+                "CCO", "c1ccncc1"]
+
+
+def enc_shape_fixtures(ns, tiny, strings):
+    """Other encoder shapes (vae_model.py:63-70: q_n_layers, q_bidir): train_enc_*.npz."""
+    for tag, extra in (('enc_bi', dict(Lq=1, bidir=True)), ('enc_l2', dict(Lq=2, bidir=False)),
+                       ('enc_bi3', dict(Lq=3, bidir=True))):
+        train_fixture(ns, tag, dict(tiny, **extra), strings, seed=11, steps=3, full=True)
+
+
 def main():
     ns = load_reference()
+    if sys.argv[1:] == ['enc']:      # only the encoder-shape fixtures (the others are byte-stable, no need to rewrite them)
+        tiny = dict(Hq=32, Dz=16, Hd=64, L=3)
+        return enc_shape_fixtures(ns, tiny, TINY_STRINGS)
     vocab_fixture(ns)
     tiny = dict(Hq=32, Dz=16, Hd=64, L=3)
     real = dict(Hq=256, Dz=128, Hd=512, L=3)
-    tiny_strings = ["CCl", "c1ccccc1Br", "C[nH]1cccc1", "N[C@@H](C)C(=O)O", "C", "CC(=O)Oc1ccccc1C(=O)O", "C#N", "OO",
-                    "CCO", "c1ccncc1"]
+    tiny_strings = TINY_STRINGS
     train_fixture(ns, 'tiny', tiny, tiny_strings, seed=1, steps=3, full=True)
     train_fixture(ns, 'real', real, O.synthetic_smiles(24, seed=7), seed=2, steps=3, full=False)
+    enc_shape_fixtures(ns, tiny, tiny_strings)
     sample_fixture(ns, 'tiny', tiny, n=12, seed=3, max_len=24, eos_bias=2.0)
     sample_fixture(ns, 'real', real, n=16, seed=4, max_len=100, eos_bias=3.0)
     sample_fixture(ns, 'real_t07', real, n=8, seed=5, max_len=60, temp=0.7, eos_bias=0.0)

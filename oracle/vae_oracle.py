@@ -114,15 +114,18 @@ def _pad(seqs, pad=None):
     return x, lens
 
 
-def _gru_forward(x_in, lens, h0, w_ih, w_hh, b_ih, b_hh, keep=True):
+def _gru_forward(x_in, lens, h0, w_ih, w_hh, b_ih, b_hh, keep=True, reverse=False):
     """Runs one GRU layer over padded [B,T,I] inputs with packed semantics: row b only steps
-    while t < lens[b]; outputs past the length are zero (pad_packed_sequence)."""
+    while t < lens[b]; outputs past the length are zero (pad_packed_sequence).  reverse=True is the
+    second direction of nn.GRU(bidirectional=True) on a PackedSequence: t runs T-1 .. 0, so row b
+    starts from h0 at its own last token (each sequence reversed within its length); cache[t] and
+    out[:, t] stay indexed by t."""
     B, T, _ = x_in.shape
     H = w_hh.shape[1]
     h = h0.copy()
     out = np.zeros((B, T, H), dtype=x_in.dtype)
-    cache = []
-    for t in range(T):
+    cache = [None] * T if keep else []
+    for t in (range(T - 1, -1, -1) if reverse else range(T)):
         act = lens > t
         gi = x_in[:, t] @ w_ih.T + b_ih
         gh = h @ w_hh.T + b_hh
@@ -131,20 +134,20 @@ def _gru_forward(x_in, lens, h0, w_ih, w_hh, b_ih, b_hh, keep=True):
         h = np.where(act[:, None], hp, h)
         out[:, t] = np.where(act[:, None], hp, 0.0)
         if keep:
-            cache.append((act, hprev, r, z, n, hn))
+            cache[t] = (act, hprev, r, z, n, hn)
     return out, h, cache
 
 
-def _gru_backward(d_out, d_hT, x_in, cache, w_ih, w_hh):
-    """BPTT for _gru_forward.  d_out [B,T,H] grads of outputs, d_hT [B,H] grad of final state.
-    Returns dx_in, dh0, dw_ih, dw_hh, db_ih, db_hh."""
+def _gru_backward(d_out, d_hT, x_in, cache, w_ih, w_hh, reverse=False):
+    """BPTT for _gru_forward (reverse: of its reverse direction, so t runs 0 .. T-1).  d_out [B,T,H]
+    grads of outputs, d_hT [B,H] grad of final state.  Returns dx_in, dh0, dw_ih, dw_hh, db_ih, db_hh."""
     B, T, _ = x_in.shape
     H = w_hh.shape[1]
     dw_ih = np.zeros_like(w_ih); dw_hh = np.zeros_like(w_hh)
     db_ih = np.zeros(3 * H, dtype=w_ih.dtype); db_hh = np.zeros(3 * H, dtype=w_ih.dtype)
     dx = np.zeros_like(x_in)
     dh = d_hT.copy()
-    for t in range(T - 1, -1, -1):
+    for t in (range(T) if reverse else range(T - 1, -1, -1)):
         act, hprev, r, z, n, hn = cache[t]
         m = act[:, None]
         dht = np.where(m, dh + d_out[:, t], 0.0)     # grad wrt h_t for stepping rows
@@ -164,20 +167,45 @@ def _gru_backward(d_out, d_hT, x_in, cache, w_ih, w_hh):
     return dx, dh, dw_ih, dw_hh, db_ih, db_hh
 
 
-def encoder_forward(P, seqs, eps, keep=True):
-    """vae_model.py:216-239.  seqs: list of int arrays (bos..eos); eps [B,Dz] replaces randn_like.
-    Returns dict(z, kl, mu, logvar, h) (+ cache)."""
+def encoder_shape(P):
+    """(q_n_layers, q_bidir) read off the parameter names (vae_model.py:63-70)."""
+    Lq = 0
+    while 'encoder_rnn.weight_ih_l%d' % Lq in P:
+        Lq += 1
+    return Lq, 'encoder_rnn.weight_ih_l0_reverse' in P
+
+
+def encoder_forward(P, seqs, eps, keep=True, drop_masks=None):
+    """vae_model.py:216-239 for any encoder shape of vae_model.py:63-70.  seqs: list of int arrays (bos..eos);
+    eps [B,Dz] replaces randn_like.  drop_masks: optional list (len Lq-1) of [B,T,Hq*dirs] multiplicative masks
+    (already scaled) on the outputs of layers 0..Lq-2 (nn.GRU's inter-layer dropout, q_dropout).  The heads read the
+    last layer's final states, forward then reverse (vae_model.py:228-229).
+    Returns dict(z, kl, mu, logvar, h) (+ caches)."""
     x, lens = _pad(seqs)
     emb = P['x_emb.weight'][x]
+    Lq, bidir = encoder_shape(P)
     Hq = P['encoder_rnn.weight_hh_l0'].shape[1]
     h0 = np.zeros((len(seqs), Hq), dtype=emb.dtype)
-    _, h, cache = _gru_forward(emb, lens, h0, P['encoder_rnn.weight_ih_l0'], P['encoder_rnn.weight_hh_l0'],
-                               P['encoder_rnn.bias_ih_l0'], P['encoder_rnn.bias_hh_l0'], keep)
+    layers = []
+    inp = emb
+    for l in range(Lq):
+        outs, fins, caches = [], [], []
+        for sfx in (('', '_reverse') if bidir else ('',)):
+            nm = 'encoder_rnn.%%s_l%d%s' % (l, sfx)
+            out, hT, cache = _gru_forward(inp, lens, h0, P[nm % 'weight_ih'], P[nm % 'weight_hh'], P[nm % 'bias_ih'],
+                                          P[nm % 'bias_hh'], keep, reverse=bool(sfx))
+            outs.append(out); fins.append(hT); caches.append(cache)
+        layers.append((inp, caches))
+        inp = np.concatenate(outs, axis=-1)
+        if drop_masks is not None and l < Lq - 1:
+            inp = inp * drop_masks[l]
+    h = np.concatenate(fins, axis=-1)
     mu = h @ P['q_mu.weight'].T + P['q_mu.bias']
     logvar = h @ P['q_logvar.weight'].T + P['q_logvar.bias']
     z = mu + np.exp(logvar / 2) * eps
     kl = 0.5 * (np.exp(logvar) + mu ** 2 - 1 - logvar).sum(1).mean()
-    return dict(z=z, kl=kl, mu=mu, logvar=logvar, h=h, x=x, lens=lens, emb=emb, cache=cache, eps=eps)
+    return dict(z=z, kl=kl, mu=mu, logvar=logvar, h=h, x=x, lens=lens, emb=emb, cache=layers[0][1][0], eps=eps,
+                layers=layers, drop_masks=drop_masks)
 
 
 def n_decoder_layers(P):
@@ -220,9 +248,9 @@ def decoder_forward(P, seqs, z, drop_masks=None, keep=True):
                 count=count, drop_masks=drop_masks)
 
 
-def vae_forward(P, seqs, eps, drop_masks=None):
+def vae_forward(P, seqs, eps, drop_masks=None, enc_drop_masks=None):
     """vae_model.py:151-166 -> (kl, recon) plus caches."""
-    enc = encoder_forward(P, seqs, eps)
+    enc = encoder_forward(P, seqs, eps, drop_masks=enc_drop_masks)
     dec = decoder_forward(P, seqs, enc['z'], drop_masks)
     return enc, dec
 
@@ -286,15 +314,28 @@ def vae_backward(P, enc, dec, g_kl=1.0, g_recon=1.0):
     G['q_logvar.weight'] = dlv.T @ h
     G['q_logvar.bias'] = dlv.sum(0)
     dh = dmu @ P['q_mu.weight'] + dlv @ P['q_logvar.weight']
-    # ---- encoder GRU
+    # ---- encoder GRU stack: the final-state gradient enters the last layer, forward half | reverse half
     Te = enc['x'].shape[1]
-    dxe, _, dwi, dwh, dbi, dbh = _gru_backward(np.zeros((B, Te, h.shape[1]), dtype=h.dtype), dh, enc['emb'],
-                                               enc['cache'], P['encoder_rnn.weight_ih_l0'],
-                                               P['encoder_rnn.weight_hh_l0'])
-    G['encoder_rnn.weight_ih_l0'] = dwi
-    G['encoder_rnn.weight_hh_l0'] = dwh
-    G['encoder_rnn.bias_ih_l0'] = dbi
-    G['encoder_rnn.bias_hh_l0'] = dbh
+    Lq, bidir = encoder_shape(P)
+    Hq = P['encoder_rnn.weight_hh_l0'].shape[1]
+    sfxs = ('', '_reverse') if bidir else ('',)
+    d_outs = np.zeros((B, Te, Hq * len(sfxs)), dtype=h.dtype)
+    for l in range(Lq - 1, -1, -1):
+        inp, caches = enc['layers'][l]
+        if enc['drop_masks'] is not None and l < Lq - 1:
+            d_outs = d_outs * enc['drop_masks'][l]
+        dxe = np.zeros_like(inp)
+        for k, sfx in enumerate(sfxs):
+            nm = 'encoder_rnn.%%s_l%d%s' % (l, sfx)
+            d_fin = dh[:, k * Hq:(k + 1) * Hq] if l == Lq - 1 else np.zeros((B, Hq), dtype=h.dtype)
+            dx, _, dwi, dwh, dbi, dbh = _gru_backward(d_outs[..., k * Hq:(k + 1) * Hq], d_fin, inp, caches[k],
+                                                      P[nm % 'weight_ih'], P[nm % 'weight_hh'], reverse=bool(sfx))
+            G[nm % 'weight_ih'] = dwi
+            G[nm % 'weight_hh'] = dwh
+            G[nm % 'bias_ih'] = dbi
+            G[nm % 'bias_hh'] = dbh
+            dxe = dxe + dx
+        d_outs = dxe
     np.add.at(demb, enc['x'].reshape(-1), dxe.reshape(B * Te, -1))
     demb[PAD] = 0.0          # nn.Embedding(padding_idx=pad), vae_model.py:54
     G['x_emb.weight'] = demb
@@ -303,12 +344,18 @@ def vae_backward(P, enc, dec, g_kl=1.0, g_recon=1.0):
 
 PARAM_ORDER_HEAD = ['x_emb.weight', 'encoder_rnn.weight_ih_l0', 'encoder_rnn.weight_hh_l0',
                     'encoder_rnn.bias_ih_l0', 'encoder_rnn.bias_hh_l0', 'q_mu.weight', 'q_mu.bias',
-                    'q_logvar.weight', 'q_logvar.bias', 'decoder_lat.weight', 'decoder_lat.bias']
+                    'q_logvar.weight', 'q_logvar.bias', 'decoder_lat.weight', 'decoder_lat.bias']   # the default shape
 
 
 def param_order(P):
-    """Order of model.vae.parameters() (vae_model.py:101-115) = optimiser order (vae_trainer.py:99-100)."""
-    names = list(PARAM_ORDER_HEAD)
+    """Order of model.vae.parameters() (vae_model.py:101-115) = optimiser order (vae_trainer.py:99-100); nn.GRU lists
+    weight_ih, weight_hh, bias_ih, bias_hh per layer, forward then reverse."""
+    Lq, bidir = encoder_shape(P)
+    names = ['x_emb.weight']
+    for l in range(Lq):
+        for sfx in (('', '_reverse') if bidir else ('',)):
+            names += ['encoder_rnn.%s_l%d%s' % (k, l, sfx) for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
+    names += ['q_mu.weight', 'q_mu.bias', 'q_logvar.weight', 'q_logvar.bias', 'decoder_lat.weight', 'decoder_lat.bias']
     for l in range(n_decoder_layers(P)):
         names += ['decoder_rnn.%s_l%d' % (k, l) for k in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh')]
     names += ['decoder_fc.weight', 'decoder_fc.bias']
@@ -441,18 +488,23 @@ def synthetic_smiles(n, seed=20250310):
     return out
 
 
-def init_params(seed=0, V=N_VOCAB, Hq=256, Dz=128, Hd=512, L=3, dtype=np.float32):
-    """Random parameters with torch's default init ranges (uniform +-1/sqrt(H)); x_emb = eye."""
+def init_params(seed=0, V=N_VOCAB, Hq=256, Dz=128, Hd=512, L=3, dtype=np.float32, Lq=1, bidir=False):
+    """Random parameters with torch's default init ranges (uniform +-1/sqrt(H)); x_emb = eye.  Lq / bidir: the
+    encoder shape (q_n_layers, q_bidir); the default shape draws exactly what it always drew."""
     rng = np.random.default_rng(seed)
 
     def U(shape, k):
         return rng.uniform(-k, k, size=shape).astype(dtype)
     P = {'x_emb.weight': np.eye(V, dtype=dtype)}
     k = 1 / math.sqrt(Hq)
-    P['encoder_rnn.weight_ih_l0'] = U((3 * Hq, V), k); P['encoder_rnn.weight_hh_l0'] = U((3 * Hq, Hq), k)
-    P['encoder_rnn.bias_ih_l0'] = U((3 * Hq,), k); P['encoder_rnn.bias_hh_l0'] = U((3 * Hq,), k)
+    nd = 2 if bidir else 1
+    for l in range(Lq):
+        for sfx in (('', '_reverse') if bidir else ('',)):
+            nm = 'encoder_rnn.%%s_l%d%s' % (l, sfx)
+            P[nm % 'weight_ih'] = U((3 * Hq, V if l == 0 else Hq * nd), k); P[nm % 'weight_hh'] = U((3 * Hq, Hq), k)
+            P[nm % 'bias_ih'] = U((3 * Hq,), k); P[nm % 'bias_hh'] = U((3 * Hq,), k)
     for nm in ('q_mu', 'q_logvar'):
-        P[nm + '.weight'] = U((Dz, Hq), k); P[nm + '.bias'] = U((Dz,), k)
+        P[nm + '.weight'] = U((Dz, Hq * nd), k); P[nm + '.bias'] = U((Dz,), k)
     k = 1 / math.sqrt(Dz)
     P['decoder_lat.weight'] = U((Hd, Dz), k); P['decoder_lat.bias'] = U((Hd,), k)
     k = 1 / math.sqrt(Hd)

@@ -4,12 +4,19 @@
 #include "pg_common.h"
 
 struct ParamOff {
-  long x_emb, enc_wih, enc_whh, enc_bih, enc_bhh, qmu_w, qmu_b, qlv_w, qlv_b, lat_w, lat_b;
+  long x_emb, enc_wih, enc_whh, enc_bih, enc_bhh, qmu_w, qmu_b, qlv_w, qlv_b, lat_w, lat_b;   // enc_* = layer 0, forward
+  // every (layer, direction) of the encoder GRU, nn.GRU's parameter order (weight_ih_l{l}[_reverse], weight_hh, bias_ih, bias_hh)
+  long g_wih[PG_MAX_ENC_LAYERS][2], g_whh[PG_MAX_ENC_LAYERS][2], g_bih[PG_MAX_ENC_LAYERS][2], g_bhh[PG_MAX_ENC_LAYERS][2];
   long dec_wih[PG_MAX_LAYERS], dec_whh[PG_MAX_LAYERS], dec_bih[PG_MAX_LAYERS], dec_bhh[PG_MAX_LAYERS];
   long fc_w, fc_b, total;
 };
 
 static inline int vpad(const pg_dims* d) { return 64; }
+// encoder shape (vae_model.py:63-81); 0 / 0 in pg_dims = one layer, one direction
+static inline int enc_layers(const pg_dims* d) { return d->Lq > 0 ? d->Lq : 1; }
+static inline int enc_dirs(const pg_dims* d) { return d->qbidir ? 2 : 1; }
+static inline bool enc_generic(const pg_dims* d) { return enc_layers(d) > 1 || enc_dirs(d) > 1; }
+static inline int enc_in(const pg_dims* d, int l) { return l == 0 ? d->E : d->Hq * enc_dirs(d); }
 
 static inline int check_dims(const pg_dims* d, int dtype) {
   PG_REQUIRE(d != nullptr, "dims is NULL");
@@ -19,6 +26,8 @@ static inline int check_dims(const pg_dims* d, int dtype) {
   PG_REQUIRE(d->L >= 1 && d->L <= PG_MAX_LAYERS, "decoder layers %d outside [1,%d]", d->L, PG_MAX_LAYERS);
   PG_REQUIRE(d->Hq >= 32 && d->Hq % 32 == 0 && d->Hd >= 32 && d->Hd % 32 == 0 && d->Dz >= 8 && d->Dz % 8 == 0,
              "hidden sizes must be multiples of 32 and d_z a multiple of 8 (got Hq=%d Hd=%d Dz=%d)", d->Hq, d->Hd, d->Dz);
+  PG_REQUIRE(d->Lq >= 0 && d->Lq <= PG_MAX_ENC_LAYERS && (d->qbidir == 0 || d->qbidir == 1),
+             "encoder shape: Lq=%d outside [0,%d] or qbidir=%d not 0/1", d->Lq, PG_MAX_ENC_LAYERS, d->qbidir);
   PG_REQUIRE(d->pad >= 0 && d->pad < d->V && d->bos >= 0 && d->bos < d->V && d->eos >= 0 && d->eos < d->V,
              "special token ids must lie in [0,V)");
   return PG_OK;
@@ -29,13 +38,20 @@ static inline ParamOff param_offsets(const pg_dims* d) {
   long p = 0;
   auto take = [&](long n) { long r = p; p += n; return r; };
   o.x_emb = take((long)d->V * d->E);
-  o.enc_wih = take(3L * d->Hq * d->E);
-  o.enc_whh = take(3L * d->Hq * d->Hq);
-  o.enc_bih = take(3L * d->Hq);
-  o.enc_bhh = take(3L * d->Hq);
-  o.qmu_w = take((long)d->Dz * d->Hq);
+  for (int l = 0; l < PG_MAX_ENC_LAYERS; ++l)
+    for (int r = 0; r < 2; ++r) o.g_wih[l][r] = o.g_whh[l][r] = o.g_bih[l][r] = o.g_bhh[l][r] = -1;
+  for (int l = 0; l < enc_layers(d); ++l)
+    for (int r = 0; r < enc_dirs(d); ++r) {
+      o.g_wih[l][r] = take(3L * d->Hq * enc_in(d, l));
+      o.g_whh[l][r] = take(3L * d->Hq * d->Hq);
+      o.g_bih[l][r] = take(3L * d->Hq);
+      o.g_bhh[l][r] = take(3L * d->Hq);
+    }
+  o.enc_wih = o.g_wih[0][0]; o.enc_whh = o.g_whh[0][0]; o.enc_bih = o.g_bih[0][0]; o.enc_bhh = o.g_bhh[0][0];
+  const long q_in = (long)d->Hq * enc_dirs(d);
+  o.qmu_w = take((long)d->Dz * q_in);
   o.qmu_b = take(d->Dz);
-  o.qlv_w = take((long)d->Dz * d->Hq);
+  o.qlv_w = take((long)d->Dz * q_in);
   o.qlv_b = take(d->Dz);
   o.lat_w = take((long)d->Hd * d->Dz);
   o.lat_b = take(d->Hd);

@@ -3,6 +3,7 @@
 #include <math.h>
 #include "pg_gemm.h"
 #include "pg_gru.h"
+#include "pg_host.h"
 #include "pg_layout.h"
 #include "pg_misc.h"
 #include "pg_mma.h"
@@ -15,18 +16,6 @@ thread_local char g_pg_err[512] = {0};
 extern "C" const char* pg_last_error(void) { return g_pg_err; }
 extern "C" int pg_version(void) { return PG_VERSION; }
 extern "C" long pg_param_count(const pg_dims* d) { return d ? param_offsets(d).total : -1; }
-
-#define PG_TRY(expr)            \
-  do {                          \
-    int _s = (expr);            \
-    if (_s != PG_OK) return _s; \
-  } while (0)
-
-template <typename T> static inline T* at(void* base, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(base) + off); }
-template <typename T> static inline const T* at(const void* base, size_t off) {
-  return reinterpret_cast<const T*>(static_cast<const char*>(base) + off);
-}
-static inline int ew_blocks(long n) { return (int)std::min<long>(cdiv(n, 256), 4096); }
 
 // ===================================================================================================
 // shadow weights
@@ -117,6 +106,8 @@ static int prepare_weights_t(const pg_dims* d, int dtype, const float* params, v
     tabs[which].d[tabs[which].n++] = c;
     if ((long)rows * cols > maxel[which]) maxel[which] = (long)rows * cols;
   };
+  const bool gen = enc_generic(d);   // other encoder shapes keep their own operand copies (pg_encgen.hip): nothing of theirs here
+  if (!gen) {
   add(0, po.enc_whh, so.enc_whh, 3 * Hq, Hq, Hq, Hq, 0, 0);
   add(0, po.enc_whh, so.enc_whhT, 3 * Hq, Hq, Hq, 3 * Hq, 1, 0);
   add(0, po.qmu_w, so.wq, Dz, Hq, Hq, Hq, 0, 0);
@@ -125,6 +116,7 @@ static int prepare_weights_t(const pg_dims* d, int dtype, const float* params, v
   add(0, po.qlv_w, so.wqT + (size_t)Dz * sizeof(T), Dz, Hq, Hq, 2 * Dz, 1, 0);
   add(0, po.qmu_b, so.bq, 1, Dz, Dz, Dz, 0, 1);
   add(0, po.qlv_b, so.bq + (size_t)Dz * 4, 1, Dz, Dz, Dz, 0, 1);
+  }
   add(1, po.lat_w, so.lat_w, Hd, Dz, Dz, Dz, 0, 0);
   add(1, po.lat_w, so.lat_wT, Hd, Dz, Dz, Hd, 1, 0);
   add(1, po.dec_wih[0] + E, so.wih0z, 3 * Hd, Dz, E + Dz, Dz, 0, 0);
@@ -142,12 +134,14 @@ static int prepare_weights_t(const pg_dims* d, int dtype, const float* params, v
   add(1, po.fc_b, so.fc_b, 1, V, V, V, 0, 1);
   PG_REQUIRE(tabs[0].n <= PG_MAX_COPY && tabs[1].n <= PG_MAX_COPY, "copy table overflow");
   // encoder part first, on the caller's stream: the encoder forward waits for nothing else
-  hipLaunchKernelGGL(copy_table_kernel<T>, dim3(std::min<int>(cdiv(maxel[0], 256), 256), tabs[0].n), dim3(256), 0, st_main, params,
-                     static_cast<char*>(shadow), tabs[0]);
-  PG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gi_table_kernel, dim3(cdiv(3 * Hq, 256), V), dim3(256), 0, st_main, params + po.x_emb, E, params + po.enc_wih, E,
-                     params + po.enc_bih, params + po.enc_bhh, Hq, at<float>(shadow, so.tab_enc));
-  PG_CHECK_LAUNCH();
+  if (!gen) {
+    hipLaunchKernelGGL(copy_table_kernel<T>, dim3(std::min<int>(cdiv(maxel[0], 256), 256), tabs[0].n), dim3(256), 0, st_main, params,
+                       static_cast<char*>(shadow), tabs[0]);
+    PG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gi_table_kernel, dim3(cdiv(3 * Hq, 256), V), dim3(256), 0, st_main, params + po.x_emb, E, params + po.enc_wih,
+                       E, params + po.enc_bih, params + po.enc_bhh, Hq, at<float>(shadow, so.tab_enc));
+    PG_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(copy_table_kernel<T>, dim3(std::min<int>(cdiv(maxel[1], 256), 256), tabs[1].n), dim3(256), 0, sd, params,
                      static_cast<char*>(shadow), tabs[1]);
   PG_CHECK_LAUNCH();
@@ -354,28 +348,6 @@ static int sv_layout_of(const void* ws) {   // -1: no forward pass with save_for
   return -1;
 }
 
-template <typename T> static int convert_to(const float* in, T* out, long n, hipStream_t st) {
-  hipLaunchKernelGGL(convert_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, st, in, out, n);
-  PG_CHECK_LAUNCH();
-  return PG_OK;
-}
-template <typename T>
-static int colsum(const T* X, long R, int C, long ld, float* out, float alpha, const float* alpha_dev, hipStream_t st) {
-  if (R <= 0) return PG_OK;
-  const int ysplit = (int)std::max<long>(1, std::min<long>(cdiv(R, 64), 128));
-  const long rpb = cdiv(R, ysplit);
-  hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(C, 64), cdiv(R, rpb)), dim3(256), 0, st, X, R, C, ld, rpb, out, alpha, alpha_dev);
-  PG_CHECK_LAUNCH();
-  return PG_OK;
-}
-static int small_gemm(const float* A, long sam, long sak, const float* Bm, long sbk, long sbn, int M, int N, int K, float* C,
-                      long ldc, int skip_row, hipStream_t st) {
-  hipLaunchKernelGGL(small_gemm_kernel, dim3(cdiv((long)M * N, 4)), dim3(256), 0, st, A, sam, sak, Bm, sbk, sbn, M, N, K, C, ldc,
-                     skip_row);
-  PG_CHECK_LAUNCH();
-  return PG_OK;
-}
-
 // ===================================================================================================
 // encoder forward
 // ===================================================================================================
@@ -452,6 +424,8 @@ extern "C" int pg_encoder_fwd(const pg_dims* d, int dtype, const float* params, 
   PG_TRY(check_dims(d, dtype));
   PG_TRY(check_persist());
   PG_REQUIRE(params && shadow && ws && d_tokens && z, "pg_encoder_fwd: NULL buffer");
+  PG_REQUIRE(!enc_generic(d), "pg_encoder_fwd serves the one-layer one-direction encoder; Lq=%d qbidir=%d goes to pg_encoder_gen_fwd",
+             d->Lq, d->qbidir);
   return dtype == PG_BF16
              ? encoder_fwd_t<bf16_t>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, d_tokens, h_lengths, eps, dp,
                                      save_for_backward, z, mu, logvar, kl, (hipStream_t)stream)
@@ -992,6 +966,8 @@ extern "C" int pg_encoder_bwd(const pg_dims* d, int dtype, const float* params, 
   PG_TRY(check_dims(d, dtype));
   PG_TRY(check_persist());
   PG_REQUIRE(params && shadow && ws && grads, "pg_encoder_bwd: NULL buffer");
+  PG_REQUIRE(!enc_generic(d), "pg_encoder_bwd serves the one-layer one-direction encoder; Lq=%d qbidir=%d goes to pg_encoder_gen_bwd",
+             d->Lq, d->qbidir);
   return dtype == PG_BF16 ? encoder_bwd_t<bf16_t>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, h_lengths, dp, dz, g_host, g_dev,
                                                   grads, (hipStream_t)stream)
                           : encoder_bwd_t<float>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, h_lengths, dp, dz, g_host, g_dev,

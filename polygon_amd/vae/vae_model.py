@@ -33,7 +33,7 @@ def get_vocabulary(data=None, device=None):
 
 
 class _Dims(ctypes.Structure):
-    _fields_ = [(k, ctypes.c_int) for k in ("V", "E", "Hq", "Dz", "Hd", "L", "pad", "bos", "eos", "unk")]
+    _fields_ = [(k, ctypes.c_int) for k in ("V", "E", "Hq", "Dz", "Hd", "L", "pad", "bos", "eos", "unk", "Lq", "qbidir")]
 
 
 class _Dp(ctypes.Structure):
@@ -125,7 +125,7 @@ class _Engine:
         return list(self.model.vae.parameters())
 
     def ensure_flat(self):
-        """Makes the 25 parameters views of one flat fp32 buffer in optimiser order (include/polygon_hip.h)."""
+        """Makes the parameters (25 for the default shapes) views of one flat fp32 buffer in optimiser order (include/polygon_hip.h)."""
         m = self.model
         ps = self.params()
         dev = ps[0].device
@@ -160,7 +160,7 @@ class _Engine:
             self.n_params = total
             self.shadow_key = None
             d = _Dims(V=len(m.vocabulary), E=m.x_emb.weight.shape[1], Hq=m.q_d_h, Dz=m.d_z, Hd=m.d_d_h, L=m.d_n_layers,
-                      pad=m.pad, bos=m.bos, eos=m.eos, unk=m.unk)
+                      pad=m.pad, bos=m.bos, eos=m.eos, unk=m.unk, Lq=int(m.q_n_layers), qbidir=int(bool(m.q_bidir)))
             self.dims = d
             L = _lib.lib()
             L.pg_param_count.restype = ctypes.c_long
@@ -171,6 +171,24 @@ class _Engine:
 
     def dtype_code(self):
         return _lib.PG_BF16 if self.model.hip_dtype == torch.bfloat16 else _lib.PG_F32
+
+    @property
+    def generic_encoder(self):
+        """True for the encoder shapes served by pg_encoder_gen_fwd / _bwd (q_n_layers > 1 or q_bidir, vae_model.py:63-70);
+        the reference's default shape has its own kernels (pg_encoder_fwd / _bwd)."""
+        m = self.model
+        return bool(m.q_bidir) or int(m.q_n_layers) != 1
+
+    @property
+    def n_enc(self):
+        """Number of leading parameters the encoder's BPTT writes: x_emb, the encoder GRU's, q_mu, q_logvar."""
+        m = self.model
+        return 1 + 4 * int(m.q_n_layers) * (2 if m.q_bidir else 1) + 4
+
+    def q_dropout(self):
+        """nn.GRU's inter-layer dropout of the encoder (vae_model.py:69): train mode and more than one layer only."""
+        m = self.model
+        return float(m.q_dropout) if (m.training and int(m.q_n_layers) > 1) else 0.0
 
     def invalidate(self):
         self.shadow_key = None
@@ -199,10 +217,37 @@ class _Engine:
             raise _lib.PolygonHipError("pg_train_workspace_bytes: " + L.pg_last_error().decode())
         return torch.empty(nbytes, dtype=torch.uint8, device=self.flat.device)
 
+    def enc_ws(self, B, n_tokens, keep=False):
+        """Workspace the encoder calls take: the training workspace for the default shape, the generic encoder's own one
+        otherwise.  keep=True reuses one buffer between calls (the fused step)."""
+        if not self.generic_encoder:
+            return None
+        L = _lib.lib()
+        L.pg_encoder_gen_workspace_bytes.restype = ctypes.c_size_t
+        need = L.pg_encoder_gen_workspace_bytes(ctypes.byref(self.dims), self.dtype_code(), int(B), ctypes.c_long(int(n_tokens)))
+        if need == 0:
+            raise _lib.PolygonHipError("pg_encoder_gen_workspace_bytes: " + L.pg_last_error().decode())
+        dev = self.flat.device
+        if not keep:
+            return torch.empty(need, dtype=torch.uint8, device=dev)
+        ws = getattr(self, "_ews", None)
+        if ws is None or ws.numel() < need or ws.device != dev:
+            ws = self._ews = torch.empty(int(need * 1.25), dtype=torch.uint8, device=dev)
+        return ws
+
     # ---- raw calls ---------------------------------------------------------------------------------
-    def encoder_fwd(self, ws, batch, eps, dp, save, z, mu, logvar, kl):
+    def encoder_fwd(self, ws, batch, eps, dp, save, z, mu, logvar, kl, p_drop=0.0, seed=0):
+        """ws: the training workspace (default encoder shape) or enc_ws(...) (any other shape; p_drop / seed = q_dropout)."""
         L = _lib.lib()
         B, Tmax = batch.tokens.shape
+        if self.generic_encoder:
+            _lib.check(L.pg_encoder_gen_fwd(ctypes.byref(self.dims), self.dtype_code(), _lib.ptr(self.flat), _lib.ptr(ws),
+                                            ctypes.c_size_t(ws.numel()), B, Tmax, _lib.ptr(batch.tokens),
+                                            batch.lengths.ctypes.data_as(ctypes.c_void_p), _lib.ptr(eps),
+                                            ctypes.byref(dp) if dp is not None else None, ctypes.c_float(p_drop),
+                                            ctypes.c_uint64(seed), int(save), _lib.ptr(z), _lib.ptr(mu), _lib.ptr(logvar),
+                                            _lib.ptr(kl), _lib.stream_ptr()), "pg_encoder_gen_fwd")
+            return
         _lib.check(L.pg_encoder_fwd(ctypes.byref(self.dims), self.dtype_code(), _lib.ptr(self.flat), _lib.ptr(self.shadow),
                                     _lib.ptr(ws), ctypes.c_size_t(ws.numel()), B, Tmax, _lib.ptr(batch.tokens),
                                     batch.lengths.ctypes.data_as(ctypes.c_void_p), _lib.ptr(eps),
@@ -231,9 +276,16 @@ class _Engine:
                                     ctypes.c_uint64(seed), int(all_steps), ctypes.c_float(g_host), _lib.ptr(g_dev),
                                     _lib.ptr(grads), _lib.ptr(dz), _lib.stream_ptr()), "pg_decoder_bwd")
 
-    def encoder_bwd(self, ws, batch, dp, dz, g_host, g_dev, grads):
+    def encoder_bwd(self, ws, batch, dp, dz, g_host, g_dev, grads, p_drop=0.0, seed=0):
         L = _lib.lib()
         B, Tmax = batch.tokens.shape
+        if self.generic_encoder:
+            _lib.check(L.pg_encoder_gen_bwd(ctypes.byref(self.dims), self.dtype_code(), _lib.ptr(self.flat), _lib.ptr(ws),
+                                            ctypes.c_size_t(ws.numel()), B, Tmax, batch.lengths.ctypes.data_as(ctypes.c_void_p),
+                                            ctypes.byref(dp) if dp is not None else None, ctypes.c_float(p_drop),
+                                            ctypes.c_uint64(seed), _lib.ptr(dz), ctypes.c_float(g_host), _lib.ptr(g_dev),
+                                            _lib.ptr(grads), _lib.stream_ptr()), "pg_encoder_gen_bwd")
+            return
         _lib.check(L.pg_encoder_bwd(ctypes.byref(self.dims), self.dtype_code(), _lib.ptr(self.flat), _lib.ptr(self.shadow),
                                     _lib.ptr(ws), ctypes.c_size_t(ws.numel()), B, Tmax,
                                     batch.lengths.ctypes.data_as(ctypes.c_void_p),
@@ -244,22 +296,23 @@ class _Engine:
     def decoder_param_start(self):
         """Index in the flat buffers where the decoder-only parameters (decoder_lat .. decoder_fc) start."""
         ps = self.params()
-        return sum(p.numel() for p in ps[:9])
+        return sum(p.numel() for p in ps[:self.n_enc])
 
-    def train_step(self, batch, kl_weight, grads, eps=None, dp=None, p_drop=0.0, seed=0, comm=None):
+    def train_step(self, batch, kl_weight, grads, eps=None, dp=None, p_drop=0.0, seed=0, comm=None, q_drop=0.0, q_seed=0):
         """forward + hand-written BPTT of  kl_weight * kl + recon  into the flat ``grads`` buffer (zeroed here).
         ``comm`` (optional polygon_amd.parallel.GradComm) all-reduces the decoder bucket while the encoder BPTT
-        runs, then the encoder bucket.  Returns device scalars (kl, recon)."""
+        runs, then the encoder bucket.  p_drop / seed: the decoder's inter-layer dropout (d_dropout); q_drop / q_seed: the
+        encoder's (q_dropout, only for encoders of more than one layer).  Returns device scalars (kl, recon)."""
         L = _lib.lib()
         # deferral on for the whole step: the decoder's shadow weights are rebuilt on the library's side stream beside the
         # encoder forward, its large weight-gradient GEMMs run there beside the dz chain and the encoder BPTT
         old = L.pg_defer_weight_grads(1)
         try:
-            return self._train_step(batch, kl_weight, grads, eps, dp, p_drop, seed, comm)
+            return self._train_step(batch, kl_weight, grads, eps, dp, p_drop, seed, comm, q_drop, q_seed)
         finally:
             L.pg_defer_weight_grads(old)
 
-    def _train_step(self, batch, kl_weight, grads, eps, dp, p_drop, seed, comm):
+    def _train_step(self, batch, kl_weight, grads, eps, dp, p_drop, seed, comm, q_drop=0.0, q_seed=0):
         self.ensure_shadow()
         dev = self.flat.device
         B = len(batch)
@@ -278,8 +331,11 @@ class _Engine:
             dp = getattr(batch, "dp", None)        # a shard made by the sharding collate carries its own pg_dp
         if eps is None:
             eps = torch.randn(B, self.dims.Dz, device=dev)
+        ews = self.enc_ws(B, batch.n_tokens, keep=True)
+        if ews is None:
+            ews = ws
         grads.zero_()
-        self.encoder_fwd(ws, batch, eps, dp, 1, z, None, None, scal[0:1])
+        self.encoder_fwd(ews, batch, eps, dp, 1, z, None, None, scal[0:1], q_drop, q_seed)
         self.decoder_fwd(ws, batch, z, dp, p_drop, seed, 0, 1, scal[1:2])
         # the decoder's large weight-gradient GEMMs run on the library's side stream, beside the dz chain and the encoder
         # BPTT (joined at the end of pg_encoder_bwd).  Under data parallelism the decoder bucket's all-reduce waits for
@@ -287,7 +343,7 @@ class _Engine:
         self.decoder_bwd(ws, batch, dp, p_drop, seed, 0, 1.0, None, grads, dz)
         if comm is not None:
             comm.start_decoder_bucket(grads, self.decoder_param_start())
-        self.encoder_bwd(ws, batch, dp, dz, float(kl_weight), None, grads)
+        self.encoder_bwd(ews, batch, dp, dz, float(kl_weight), None, grads, q_drop, q_seed)
         if comm is not None:
             comm.finish(grads, self.decoder_param_start())
         return scal[0], scal[1]
@@ -310,7 +366,8 @@ class _Engine:
             dp = getattr(batch, "dp", None)
         if eps is None:
             eps = torch.randn(B, self.dims.Dz, device=dev)      # the reference draws eps in eval mode too (vae_model.py:233)
-        self.encoder_fwd(ws, batch, eps, dp, 0, z, None, None, scal[0:1])
+        ews = self.enc_ws(B, batch.n_tokens, keep=True)
+        self.encoder_fwd(ws if ews is None else ews, batch, eps, dp, 0, z, None, None, scal[0:1])
         self.decoder_fwd(ws, batch, z, dp, 0.0, 0, 0, 0, scal[1:2])
         return scal[0], scal[1]
 
@@ -327,17 +384,19 @@ class _EncoderFn(torch.autograd.Function):
     """forward_encoder with hand-written BPTT (pg_encoder_fwd / pg_encoder_bwd)."""
 
     @staticmethod
-    def forward(ctx, eng, batch, eps, need_grad, *params):
+    def forward(ctx, eng, batch, eps, need_grad, p_drop, seed, *params):
         dev = eng.flat.device
         B = len(batch)
         Dz = eng.dims.Dz
-        ws = eng.train_ws(B, batch.n_tokens)
+        ws = eng.enc_ws(B, batch.n_tokens)
+        if ws is None:
+            ws = eng.train_ws(B, batch.n_tokens)
         z = torch.empty(B, Dz, device=dev)
         mu = torch.empty(B, Dz, device=dev)
         logvar = torch.empty(B, Dz, device=dev)
         kl = torch.empty((), device=dev)
-        eng.encoder_fwd(ws, batch, eps, None, need_grad, z, mu, logvar, kl)
-        ctx.eng, ctx.batch, ctx.ws = eng, batch, ws
+        eng.encoder_fwd(ws, batch, eps, None, need_grad, z, mu, logvar, kl, p_drop, seed)
+        ctx.eng, ctx.batch, ctx.ws, ctx.cfg = eng, batch, ws, (p_drop, seed)
         ctx.mark_non_differentiable(mu, logvar)
         return z, kl, mu, logvar
 
@@ -348,11 +407,11 @@ class _EncoderFn(torch.autograd.Function):
         gkl_dev = gkl.contiguous() if gkl is not None else None
         eng.ensure_shadow()
         eng.encoder_bwd(ctx.ws, ctx.batch, None, gz.contiguous() if gz is not None else None,
-                        1.0 if gkl is not None else 0.0, gkl_dev, grads)
+                        1.0 if gkl is not None else 0.0, gkl_dev, grads, *ctx.cfg)
         gv = eng.grad_views(grads)
         # decoder-only parameters (decoder_lat .. decoder_fc) receive nothing from the encoder
-        n_enc = 9
-        return (None, None, None, None) + tuple(gv[:n_enc]) + (None,) * (len(gv) - n_enc)
+        n_enc = eng.n_enc
+        return (None,) * 6 + tuple(gv[:n_enc]) + (None,) * (len(gv) - n_enc)
 
 
 class _DecoderFn(torch.autograd.Function):
@@ -388,8 +447,8 @@ class _DecoderFn(torch.autograd.Function):
         eng.ensure_shadow()
         eng.decoder_bwd(ctx.ws, ctx.batch, None, p_drop, seed, all_steps, 1.0, grecon.contiguous(), grads, dz)
         gv = eng.grad_views(grads)
-        # encoder-only parameters (encoder_rnn, q_mu, q_logvar = indices 1..8) receive nothing from the decoder
-        pg = [gv[0]] + [None] * 8 + gv[9:]
+        # encoder-only parameters (encoder_rnn, q_mu, q_logvar = indices 1..n_enc-1) receive nothing from the decoder
+        pg = [gv[0]] + [None] * (eng.n_enc - 1) + gv[eng.n_enc:]
         return (None, None, None, None, None, None, None, dz) + tuple(pg)
 
 
@@ -442,9 +501,8 @@ class VAE(nn.Module):
         self.decoder = nn.ModuleList([self.decoder_lat, self.decoder_rnn, self.decoder_fc])
         self.vae = nn.ModuleList([self.x_emb, self.encoder, self.decoder])
 
-        if self.q_bidir or self.q_n_layers != 1:
-            raise NotImplementedError("the MI355X path implements the reference's default unidirectional 1-layer GRU "
-                                      "encoder (q_bidir=False, q_n_layers=1)")
+        if not 1 <= int(self.q_n_layers) <= 4:
+            raise ValueError("q_n_layers must be in [1, 4] (PG_MAX_ENC_LAYERS, include/polygon_hip.h), got %r" % (self.q_n_layers,))
         cd = self.compute_dtype
         if cd in ("fp32", "float32", torch.float32):
             self.__dict__['hip_dtype'] = torch.float32
@@ -515,7 +573,9 @@ class VAE(nn.Module):
             eps = torch.randn(B, self.d_z, device=eng.flat.device)
         eps = eps.to(eng.flat.device, torch.float32).contiguous()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in eng.params())
-        z, kl, mu, logvar = _EncoderFn.apply(eng, batch, eps, need_grad, *eng.params())
+        q_drop = eng.q_dropout()
+        q_seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if q_drop > 0 else 0
+        z, kl, mu, logvar = _EncoderFn.apply(eng, batch, eps, need_grad, q_drop, q_seed, *eng.params())
         if return_mu:
             return z, kl, mu
         return z, kl

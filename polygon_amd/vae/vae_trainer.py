@@ -274,8 +274,10 @@ class VAETrainer:
                 if optimizer is not None:
                     p_drop = float(model.d_dropout) if model.d_n_layers > 1 else 0.0
                     seed = int(torch.randint(0, 2 ** 62, (1,), generator=self._seed_gen()).item()) if p_drop > 0 else 0
+                    q_drop = float(model.q_dropout) if model.q_n_layers > 1 else 0.0     # nn.GRU's own rule (vae_model.py:69)
+                    q_seed = int(torch.randint(0, 2 ** 62, (1,), generator=self._seed_gen()).item()) if q_drop > 0 else 0
                     kl_loss, recon_loss = eng.train_step(b, kl_weight, optimizer.flat_grad, eps=eps, p_drop=p_drop,
-                                                         seed=seed, comm=comm)
+                                                         seed=seed, comm=comm, q_drop=q_drop, q_seed=q_seed)
                     optimizer.step()
                 else:     # validation (vae_trainer.py:246-252: eval mode, fresh eps), forward only
                     kl_loss, recon_loss = eng.eval_losses(b, eps=eps)

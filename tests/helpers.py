@@ -19,6 +19,8 @@ def build_model(dims, seed, compute_dtype="fp32", device="cuda", eos_bias=0.0, *
     if eos_bias:
         P["decoder_fc.bias"] = P["decoder_fc.bias"].copy()
         P["decoder_fc.bias"][O.EOS] += eos_bias
+    if "Lq" in dims or "bidir" in dims:        # other encoder shapes (vae_model.py:63-70)
+        kw = dict(dict(q_n_layers=dims.get("Lq", 1), q_bidir=bool(dims.get("bidir", False))), **kw)
     model = VAE(q_d_h=dims["Hq"], d_z=dims["Dz"], d_d_h=dims["Hd"], d_n_layers=dims["L"], compute_dtype=compute_dtype, **kw)
     named = canon_named(model)
     assert set(named) == set(P)

@@ -86,10 +86,39 @@ def test_constructor_errors(model):
         VAE(q_cell="lstm")
     with pytest.raises(ValueError):
         VAE(d_cell="lstm")
-    with pytest.raises(NotImplementedError):
-        VAE(q_bidir=True)
+    with pytest.raises(ValueError):
+        VAE(q_n_layers=5)                      # PG_MAX_ENC_LAYERS
     m = VAE(some_inert_flag=3)
     assert m.some_inert_flag == 3
+
+
+def test_other_encoder_shapes_keep_the_reference_layout():
+    """q_bidir / q_n_layers (vae_model.py:63-70): parameter list in nn.GRU's order, q heads on Hq*dirs, and the library's
+    flat layout (pg_param_count with pg_dims.Lq / qbidir) counts exactly those values."""
+    from oracle import vae_oracle as O
+    from polygon_amd import _lib
+    from polygon_amd.vae.vae_model import VAE, _Dims
+    m = VAE(q_bidir=True, q_n_layers=2, q_d_h=64, d_z=32, d_d_h=128)
+    P = O.init_params(0, Hq=64, Dz=32, Hd=128, L=3, Lq=2, bidir=True)
+    names = [n for n, _ in m.vae.named_parameters()]
+    assert [list(p.shape) for p in m.vae.parameters()] == [list(P[k].shape) for k in O.param_order(P)]
+    assert len(names) == m._engine.n_enc + 2 + 12 + 2 and m._engine.generic_encoder
+    assert m.q_mu.in_features == 128
+    lib = _lib.lib()
+    lib.pg_param_count.restype = ctypes.c_long
+    lib.pg_encoder_gen_workspace_bytes.restype = ctypes.c_size_t
+    d = _Dims(V=51, E=51, Hq=64, Dz=32, Hd=128, L=3, pad=49, bos=47, eos=48, unk=50, Lq=2, qbidir=1)
+    assert lib.pg_param_count(ctypes.byref(d)) == sum(p.numel() for p in m.vae.parameters())
+    assert lib.pg_encoder_gen_workspace_bytes(ctypes.byref(d), 1, 16, ctypes.c_long(400)) > 0
+    # the default encoder's entry points refuse the shape instead of misreading the layout
+    lens = np.array([5, 3], dtype=np.int32)
+    st = lib.pg_encoder_fwd(ctypes.byref(d), 0, ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8),
+                            ctypes.c_size_t(1 << 40), 2, 5, ctypes.c_void_p(8), lens.ctypes.data_as(ctypes.c_void_p), None,
+                            None, 0, ctypes.c_void_p(8), None, None, None, None)
+    assert st != 0 and b"pg_encoder_gen_fwd" in lib.pg_last_error()
+    d.Lq = 9
+    assert lib.pg_encoder_gen_workspace_bytes(ctypes.byref(d), 1, 16, ctypes.c_long(400)) == 0
+    assert b"encoder shape" in lib.pg_last_error()
 
 
 def test_cpu_model_fails_loudly(model):

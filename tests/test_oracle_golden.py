@@ -64,7 +64,25 @@ def test_param_order(vocab):
     assert sum(P[n].size for n in names) == vocab["n_params"] == 4614236
 
 
-@pytest.mark.parametrize("tag,dims,seed,full", [("tiny", TINY, 1, True), ("real", REAL, 2, False)])
+ENC_SHAPES = {"enc_bi": dict(TINY, Lq=1, bidir=True), "enc_l2": dict(TINY, Lq=2, bidir=False),
+              "enc_bi3": dict(TINY, Lq=3, bidir=True)}     # vae_model.py:63-70 with q_n_layers / q_bidir off their defaults
+
+
+def test_param_order_of_other_encoder_shapes():
+    """nn.GRU lists weight_ih, weight_hh, bias_ih, bias_hh per layer, forward then reverse; q_mu / q_logvar read Hq*dirs."""
+    P = O.init_params(0, **ENC_SHAPES["enc_bi3"])
+    names = O.param_order(P)
+    assert names[:9] == ["x_emb.weight", "encoder_rnn.weight_ih_l0", "encoder_rnn.weight_hh_l0", "encoder_rnn.bias_ih_l0",
+                         "encoder_rnn.bias_hh_l0", "encoder_rnn.weight_ih_l0_reverse", "encoder_rnn.weight_hh_l0_reverse",
+                         "encoder_rnn.bias_ih_l0_reverse", "encoder_rnn.bias_hh_l0_reverse"]
+    assert set(names) == set(P) and len(names) == len(P) == 1 + 4 * 3 * 2 + 6 + 4 * 3 + 2
+    assert P["encoder_rnn.weight_ih_l1_reverse"].shape == (96, 64) and P["q_mu.weight"].shape == (16, 64)
+    # the default shape still draws what the older fixtures were generated with
+    assert O.param_order(O.init_params(0, **TINY))[:11] == O.PARAM_ORDER_HEAD
+
+
+@pytest.mark.parametrize("tag,dims,seed,full", [("tiny", TINY, 1, True), ("real", REAL, 2, False)] +
+                         [(t, d, 11, True) for t, d in ENC_SHAPES.items()])
 def test_train_step_matches_reference(golden_dir, tag, dims, seed, full):
     g = np.load(os.path.join(golden_dir, "train_%s.npz" % tag))
     P = _P(seed, dims)
