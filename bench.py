@@ -525,6 +525,13 @@ def main():
             pool = make_pool(model, strings, nb, 0, 1, n_pool, dev)
             d, t = time_steps(eng, opt, pool, None, args.dropout, 20, 3, barrier)
             proxy["n_batch_%d" % nb] = {"ms_per_step": d / 20 * 1e3, "tokens_per_s": t / d}
+    large = None
+    if world == 1 and not args.no_proxy:   # above the persistent kernels' 1024-row limit: interleaved micro-batches (vae_model.py)
+        nb = 2048
+        strings = synthetic_smiles(4 * nb, seed=20250311)
+        pool = make_pool(model, strings, nb, 0, 1, 4, dev)
+        d, t = time_steps(eng, opt, pool, None, args.dropout, 10, 2, barrier)
+        large = {"n_batch_%d" % nb: {"ms_per_step": d / 10 * 1e3, "tokens_per_s": t / d, "micro_batches": eng.micro_batches(nb)}}
 
     e2e = None
     if not args.no_e2e:
@@ -578,6 +585,8 @@ def main():
             out["other_scaling"] = other
         if proxy is not None:
             out["strong_scaling_proxy"] = proxy
+        if large is not None:
+            out["large_batch"] = large
         if e2e is not None:
             out["e2e"] = e2e
         if configs0 is not None:

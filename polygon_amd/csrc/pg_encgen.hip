@@ -362,6 +362,9 @@ int encgen_bwd_t(const pg_dims* d, int dtype, const float* params, void* ws, siz
       PG_CHECK_LAUNCH();
     }
   }
+  // as pg_encoder_bwd: the decoder's deferred weight gradients are complete in the order of this stream from here on
+  // (a following forward pass on the same workspace may overwrite what they read)
+  PG_TRY(pg_deferred_join(st));
   return PG_OK;
 }
 

@@ -84,6 +84,18 @@ class TokenBatch(list):
         out.set_global(rank, world, len(self), self.n_tokens)
         return out
 
+    def micro(self, j, k):
+        """Rows j, j+k, ... as a batch of their own that still normalises by THIS batch's global counts and keys its
+        dropout masks by the global row (the pg_dp of a shard of a shard): gradients and losses of the k micro-batches
+        add up to the whole batch's.  Used to keep batches above the persistent kernels' row limit on those kernels."""
+        idx = torch.arange(j, len(self), k, device=self.tokens.device)
+        out = TokenBatch(self.tokens.index_select(0, idx).contiguous(), self.lengths[j::k])
+        mul, add = (self.dp.b_mul, self.dp.b_add) if self.dp is not None else (1, 0)
+        out.global_rows, out.global_tokens = self.global_rows, self.global_tokens
+        out.dp = _Dp(kl_inv_batch=1.0 / max(1, self.global_rows), ce_count=float(self.global_tokens - self.global_rows),
+                     b_mul=int(k * mul), b_add=int(j * mul + add))
+        return out
+
     def set_global(self, rank, world, global_rows, global_tokens):
         self.global_rows, self.global_tokens = int(global_rows), int(global_tokens)
         # every row contributes len-1 cross-entropy targets (the tokeniser never emits pad)
@@ -308,11 +320,34 @@ class _Engine:
         # encoder forward, its large weight-gradient GEMMs run there beside the dz chain and the encoder BPTT
         old = L.pg_defer_weight_grads(1)
         try:
-            return self._train_step(batch, kl_weight, grads, eps, dp, p_drop, seed, comm, q_drop, q_seed)
+            k = self.micro_batches(len(batch))
+            if k == 1 or dp is not None:
+                return self._train_step(batch, kl_weight, grads, eps, dp, p_drop, seed, comm, q_drop, q_seed)
+            # More rows than the one-launch recurrences take (PERSIST_MAX_ROWS): k interleaved micro-batches, each sorted and
+            # length-balanced like a data-parallel shard, accumulate into the same gradient buffer; the losses add up.
+            # The all-reduce (comm) rides on the last one, over the accumulated sums.
+            if eps is None:
+                eps = torch.randn(len(batch), self.dims.Dz, device=self.flat.device)
+            kl = recon = None
+            for j in range(k):
+                a, b = self._train_step(batch.micro(j, k), kl_weight, grads, eps[j::k].contiguous(), None, p_drop, seed,
+                                        comm if j == k - 1 else None, q_drop, q_seed, zero=(j == 0))
+                kl, recon = (a.clone(), b.clone()) if j == 0 else (kl + a, recon + b)
+            return kl, recon
         finally:
             L.pg_defer_weight_grads(old)
 
-    def _train_step(self, batch, kl_weight, grads, eps, dp, p_drop, seed, comm, q_drop=0.0, q_seed=0):
+    PERSIST_MAX_ROWS = 1024     # dec_persist_supported (pg_persist_dec.hip): rows per launch of the persistent decoder kernels
+
+    def micro_batches(self, B):
+        """Number of micro-batches the fused step splits B rows into: 1 unless the bf16 persistent decoder kernels cover
+        this model and B exceeds their row limit (fp32 and other shapes run the per-step kernels, which take any B)."""
+        m = self.model
+        if self.dtype_code() != _lib.PG_BF16 or int(m.d_d_h) != 512 or not 1 <= int(m.d_n_layers) <= 4:
+            return 1
+        return max(1, -(-int(B) // self.PERSIST_MAX_ROWS))
+
+    def _train_step(self, batch, kl_weight, grads, eps, dp, p_drop, seed, comm, q_drop=0.0, q_seed=0, zero=True):
         self.ensure_shadow()
         dev = self.flat.device
         B = len(batch)
@@ -334,7 +369,8 @@ class _Engine:
         ews = self.enc_ws(B, batch.n_tokens, keep=True)
         if ews is None:
             ews = ws
-        grads.zero_()
+        if zero:
+            grads.zero_()
         self.encoder_fwd(ews, batch, eps, dp, 1, z, None, None, scal[0:1], q_drop, q_seed)
         self.decoder_fwd(ws, batch, z, dp, p_drop, seed, 0, 1, scal[1:2])
         # the decoder's large weight-gradient GEMMs run on the library's side stream, beside the dz chain and the encoder
@@ -351,6 +387,13 @@ class _Engine:
     def eval_losses(self, batch, eps=None, dp=None):
         """(kl, recon) of a batch, forward only (no activations saved, no dropout): the validation pass of the fused
         trainer.  With ``dp`` the values are this rank's share of the global-batch losses (sum over ranks = global)."""
+        k = self.micro_batches(len(batch)) if dp is None else 1
+        if k > 1:     # as train_step: keep every launch within the persistent kernels' row limit
+            self.ensure_flat()
+            if eps is None:
+                eps = torch.randn(len(batch), self.dims.Dz, device=self.flat.device)
+            parts = [self.eval_losses(batch.micro(j, k), eps[j::k].contiguous()) for j in range(k)]
+            return sum(p[0] for p in parts), sum(p[1] for p in parts)
         self.ensure_shadow()
         dev = self.flat.device
         B = len(batch)

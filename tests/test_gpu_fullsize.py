@@ -144,3 +144,51 @@ def test_sampler_chunk_loop_equals_separate_calls():
     b = model.sample_tokens(n - CH, max_len=max_len, z=z[CH:], seed=5, row_offset=100 + CH)
     assert torch.equal(tok2, torch.cat([a[0], b[0]])) and torch.equal(ep2, torch.cat([a[1], b[1]]))
     assert not torch.equal(tok2, tok)
+
+
+@pytest.mark.parametrize("generic", [False, True], ids=["default_encoder", "bidir_encoder"])
+def test_batches_above_the_persistent_row_limit_run_as_micro_batches(generic):
+    """n_batch 2500 > 1024 rows (dec_persist_supported): the fused bf16 step splits the batch into 3 interleaved
+    micro-batches that all run the one-launch recurrences and accumulate into one gradient buffer.  Checked against the
+    per-step kernels on the whole batch (pg_persist_disable(7), which take any B): same losses and gradients, dropout on
+    (the masks are keyed by the row's index in the whole batch, so the split does not move them)."""
+    import ctypes
+    from polygon_amd import _lib
+    from polygon_amd.vae.vae_trainer import FusedClipAdam
+    dims = dict(REAL, Lq=2, bidir=True) if generic else REAL
+    model, _ = build_model(dims, 31, "bf16", d_dropout=0.2, q_dropout=0.1)
+    model.train()
+    n = 2500
+    batch = model.get_collate_fn()(list(O.synthetic_smiles(n, seed=77)))
+    eps = torch.randn(n, REAL["Dz"], generator=torch.Generator().manual_seed(5)).cuda()
+    opt = FusedClipAdam(model, lr=0.0)
+    eng = model._engine
+    assert eng.micro_batches(n) == 3 and eng.micro_batches(1024) == 1
+    kw = dict(p_drop=0.2, seed=4242, q_drop=0.1 if generic else 0.0, q_seed=99)
+    L = _lib.lib()
+    L.pg_profile_enable(1)
+    try:
+        kl, rec = [x.item() for x in eng.train_step(batch, 0.5, opt.flat_grad, eps=eps, **kw)]
+        torch.cuda.synchronize()
+        ms, launches, flop, seg = ctypes.c_double(), ctypes.c_long(), ctypes.c_double(), ctypes.c_int()
+        _lib.check(L.pg_profile_read(0, ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(flop), ctypes.byref(seg)), "profile")
+        assert (seg.value, launches.value) == (3, 3), (seg.value, launches.value)      # three one-launch forward recurrences
+    finally:
+        L.pg_profile_enable(0)
+    got = opt.flat_grad.clone()
+    old = L.pg_persist_disable(7)
+    try:
+        eng.micro_batches = lambda B: 1
+        kl0, rec0 = [x.item() for x in eng.train_step(batch, 0.5, opt.flat_grad, eps=eps, **kw)]
+        torch.cuda.synchronize()
+    finally:
+        L.pg_persist_disable(old)
+        del eng.micro_batches
+    assert abs(kl - kl0) <= 2e-3 * abs(kl0) and abs(rec - rec0) <= 2e-3 * abs(rec0), (kl, kl0, rec, rec0)
+    worst = max((rel_err(a, b), name) for a, b, (name, _) in
+                zip(eng.grad_views(got), eng.grad_views(opt.flat_grad), model.vae.named_parameters()))
+    assert worst[0] <= 1e-2, worst
+    # forward-only (validation) path: same split, same sums
+    model.eval()
+    k1, r1 = [x.item() for x in eng.eval_losses(batch, eps=eps)]
+    assert abs(k1 - kl0) <= 2e-2 * abs(kl0)        # (train mode above had q_dropout on for the bidirectional encoder)
