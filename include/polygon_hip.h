@@ -50,7 +50,12 @@ extern "C" {
 #define PG_MAX_LAYERS 8
 #define PG_MAX_T 511  /* longest sequence (bos..eos) the packed scheduler accepts */
 #define PG_MAX_ENC_LAYERS 4 /* q_n_layers limit of the generic encoder */
-#define PG_MAX_V 64   /* vocabulary limit of the softmax / cross-entropy / draw kernels */
+#define PG_MAX_V 128  /* vocabulary limit of the softmax / cross-entropy / draw kernels */
+/* Padded vocabulary width Vp of the logits, probabilities and one-hot rows: 64 for V <= 64, else 128.  V <= 64 (the
+ * reference's alphabet has 51 symbols) is the tuned case: fused projection + cross entropy, one-launch sampler; above it
+ * the projection is a plain GEMM, the cross entropy and the draw take two vocabulary entries per lane, and pg_sample
+ * runs the per-step kernels. */
+#define PG_VPAD(V) ((V) <= 64 ? 64 : 128)
 
 typedef struct pg_dims {
   int V, E, Hq, Dz, Hd, L; /* vocab, embedding dim, encoder hidden, latent, decoder hidden, decoder layers */
@@ -97,7 +102,7 @@ PG_API int pg_encoder_fwd(const pg_dims* d, int dtype, const float* params, cons
  * vocab projection, log-softmax, cross entropy with ignore_index=pad.  p_drop/seed: inter-layer
  * dropout of nn.GRU in train mode (vae_model.py:90).  all_steps=1 also runs each row's last (eos
  * input) step, which only matters when the logits are read back (return_y).  logits_packed (nullable)
- * receives the device address of the packed [sum(steps), 64] fp32 logits inside the workspace. */
+ * receives the device address of the packed [sum(steps), PG_VPAD(V)] fp32 logits inside the workspace. */
 PG_API int pg_decoder_fwd(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes,
                           int B, int Tmax, const int32_t* d_tokens, const int32_t* h_lengths, const float* z,
                           const pg_dp* dp, float p_drop, uint64_t seed, int all_steps, int save_for_backward,
@@ -169,8 +174,8 @@ PG_API int pg_sample(const pg_dims* d, int dtype, const float* params, const voi
  * kernels themselves (per-step and one-launch alike) can be compared with a CPU oracle step by step, which free-running
  * bf16 decoding cannot be (one differently rounded draw diverges the row).  forced (nullable) uint8 [n, max_len]: the token
  * FED to step i+1 is forced[row*max_len + i] instead of the drawn one (the drawn token is still what tokens/end_pads
- * record).  probs_out (nullable, multinomial only) float [max_len-1, n, 64]: softmax(y/temp) of step i at
- * probs_out[((i-1)*n + row)*64 + v], entries >= V zero.  Both NULL: exactly pg_sample. */
+ * record).  probs_out (nullable, multinomial only) float [max_len-1, n, Vp], Vp = PG_VPAD(V): softmax(y/temp) of step i at
+ * probs_out[((i-1)*n + row)*Vp + v], entries >= V zero.  Both NULL: exactly pg_sample. */
 PG_API int pg_sample_forced(const pg_dims* d, int dtype, const float* params, const void* shadow, void* ws, size_t ws_bytes,
                             int n, int max_len, const float* z, const float* uniforms, uint64_t seed, long row_offset,
                             float temp, int multinomial, uint8_t* tokens, int32_t* end_pads, const uint8_t* forced,

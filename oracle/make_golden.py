@@ -44,7 +44,12 @@ def load_params(model, P):
             p.copy_(torch.from_numpy(np.asarray(P[k], dtype=np.float32)))
 
 
-def build(ns, dims, seed):
+def build(ns, dims, seed, vocab=None):
+    if vocab is not None:     # a data-derived vocabulary (vae_model.py:9-20, OneHotVocab.from_data): V = E = len(vocab)
+        P = O.init_params(seed=seed, V=len(vocab), **dims)
+        model = ns.VAE(vocabulary=vocab, q_d_h=dims['Hq'], d_z=dims['Dz'], d_d_h=dims['Hd'], d_n_layers=dims['L'])
+        load_params(model, P)
+        return model, P
     P = O.init_params(seed=seed, **dims)
     # q_dropout = 0 for the encoder shapes with more than one layer: torch's own dropout stream cannot be pinned from
     # outside (the dropout path is pinned through pg_dropout_masks_host instead, as the decoder's)
@@ -109,8 +114,8 @@ def vocab_fixture(ns):
         json.dump(rec, f, indent=0)
 
 
-def train_fixture(ns, tag, dims, strings, seed, steps=3, kl_w=0.37, full=True):
-    model, P = build(ns, dims, seed)
+def train_fixture(ns, tag, dims, strings, seed, steps=3, kl_w=0.37, full=True, vocab=None, extra=None):
+    model, P = build(ns, dims, seed, vocab)
     model.train()
     data = list(strings)
     batch = model.get_collate_fn()(data)
@@ -118,6 +123,15 @@ def train_fixture(ns, tag, dims, strings, seed, steps=3, kl_w=0.37, full=True):
     rng = np.random.default_rng(seed + 100)
     eps_all = rng.standard_normal((steps, B, dims['Dz'])).astype(np.float32)
     out = {'strings': np.array(strings), 'eps': eps_all, 'kl_w': np.float32(kl_w)}
+    if vocab is not None:     # the ids the reference's own tokeniser and collate produce, and its special ids
+        T = max(len(t) for t in batch)
+        ids = np.full((B, T), model.pad, dtype=np.int64)
+        for i, t in enumerate(batch):
+            ids[i, :len(t)] = t.numpy()
+        out.update(ids=ids, lens=np.array([len(t) for t in batch]), specials=np.array([model.bos, model.eos, model.pad, model.unk]),
+                   alphabet=np.array([vocab.i2c[i] for i in range(len(vocab))]))
+    if extra:
+        out.update(extra(model))
     # forward intermediates on step 0
     with patched_eps(eps_all[0]):
         z, kl, mu = model.forward_encoder(batch, return_mu=True)
@@ -198,6 +212,51 @@ TINY_STRINGS = ["CCl", "c1ccccc1Br", "C[nH]1cccc1", "N[C@@H](C)C(=O)O", "C", "CC
                 "CCO", "c1ccncc1"]
 
 
+def wide_vocab_fixture(ns):
+    """train_wide.npz: a data-derived vocabulary of 92 characters + 4 specials = 96 symbols (> 64: the second lane's worth
+    of the softmax / cross-entropy / draw kernels), tiny hidden sizes; plus argmax and pinned-multinomial sample strings."""
+    rng = np.random.default_rng(2025)
+    chars = [chr(c) for c in range(33, 127) if chr(c) not in '<>']          # 92 printable characters
+    strings = [''.join(rng.choice(chars, size=int(n))) for n in rng.integers(1, 40, size=14)]
+    strings[0] = ''.join(chars[:46])
+    strings[1] = ''.join(chars[46:])                                         # every character occurs
+    vocab = ns.moses_utils.OneHotVocab.from_data(strings)
+    assert len(vocab) == 96, len(vocab)
+    dims = dict(Hq=32, Dz=16, Hd=64, L=3)
+
+    def sampler(model):
+        model.eval()
+        r = np.random.default_rng(77)
+        n, max_len = 10, 30
+        z = r.standard_normal((n, dims['Dz'])).astype(np.float32)
+        u = r.random((max_len - 1, n)).astype(np.float32)
+        step = {'i': 0}
+
+        def fake_multinomial(p, num):
+            i = step['i']
+            p32 = p.detach().numpy().astype(np.float32)
+            cdf = np.cumsum(p32, axis=1, dtype=np.float32)
+            for row in range(p32.shape[0]):
+                if np.min(np.abs(cdf[row] - u[i, row])) < 1e-3:
+                    kbig = int(np.argmax(p32[row]))
+                    lo = cdf[row, kbig - 1] if kbig > 0 else 0.0
+                    u[i, row] = np.float32(0.5 * (lo + cdf[row, kbig]))
+            k, _ = O.inverse_cdf_draw(p32, u[i])
+            step['i'] += 1
+            return torch.from_numpy(k)[:, None]
+        orig = torch.multinomial
+        torch.multinomial = fake_multinomial
+        try:
+            s_m = model.sample(n, max_len=max_len, z=torch.from_numpy(z))
+        finally:
+            torch.multinomial = orig
+        s_a = model.sample(n, max_len=max_len, z=torch.from_numpy(z), multinomial=False)
+        model.train()
+        return dict(sample_z=z, sample_u=u, sample_strings=np.array(s_m), sample_strings_argmax=np.array(s_a),
+                    sample_max_len=max_len)
+    train_fixture(ns, 'wide', dims, strings[2:] + strings[:2], seed=21, steps=3, full=True, vocab=vocab, extra=sampler)
+
+
 def enc_shape_fixtures(ns, tiny, strings):
     """Other encoder shapes (vae_model.py:63-70: q_n_layers, q_bidir): train_enc_*.npz."""
     for tag, extra in (('enc_bi', dict(Lq=1, bidir=True)), ('enc_l2', dict(Lq=2, bidir=False)),
@@ -207,6 +266,8 @@ def enc_shape_fixtures(ns, tiny, strings):
 
 def main():
     ns = load_reference()
+    if sys.argv[1:] == ['wide']:
+        return wide_vocab_fixture(ns)
     if sys.argv[1:] == ['enc']:      # only the encoder-shape fixtures (the others are byte-stable, no need to rewrite them)
         tiny = dict(Hq=32, Dz=16, Hd=64, L=3)
         return enc_shape_fixtures(ns, tiny, TINY_STRINGS)
@@ -217,6 +278,7 @@ def main():
     train_fixture(ns, 'tiny', tiny, tiny_strings, seed=1, steps=3, full=True)
     train_fixture(ns, 'real', real, O.synthetic_smiles(24, seed=7), seed=2, steps=3, full=False)
     enc_shape_fixtures(ns, tiny, tiny_strings)
+    wide_vocab_fixture(ns)
     sample_fixture(ns, 'tiny', tiny, n=12, seed=3, max_len=24, eos_bias=2.0)
     sample_fixture(ns, 'real', real, n=16, seed=4, max_len=100, eos_bias=3.0)
     sample_fixture(ns, 'real_t07', real, n=8, seed=5, max_len=60, temp=0.7, eos_bias=0.0)

@@ -35,6 +35,26 @@ N_VOCAB = len(ALL_SYMS)
 BOS, EOS, PAD, UNK = C2I[BOS_S], C2I[EOS_S], C2I[PAD_S], C2I[UNK_S]
 
 
+class vocabulary:
+    """Context manager: restates the tokeniser over the characters of a data-derived vocabulary
+    (OneHotVocab.from_data, moses_utils.py:25-42: sorted characters, then the four specials) for its duration.
+    Every function below looks the table up at call time."""
+
+    def __init__(self, chars):
+        self.syms = sorted(set(chars) - {BOS_S, EOS_S, PAD_S, UNK_S}) + [BOS_S, EOS_S, PAD_S, UNK_S]
+
+    def __enter__(self):
+        g = globals()
+        self.saved = {k: g[k] for k in ('ALL_SYMS', 'C2I', 'I2C', 'N_VOCAB', 'BOS', 'EOS', 'PAD', 'UNK')}
+        c2i = {c: i for i, c in enumerate(self.syms)}
+        g.update(ALL_SYMS=self.syms, C2I=c2i, I2C={i: c for i, c in enumerate(self.syms)}, N_VOCAB=len(self.syms),
+                 BOS=c2i[BOS_S], EOS=c2i[EOS_S], PAD=c2i[PAD_S], UNK=c2i[UNK_S])
+        return self
+
+    def __exit__(self, *a):
+        globals().update(self.saved)
+
+
 def string2ids(string, add_bos=False, add_eos=False):
     """moses_utils.py:63-83 -- per CHARACTER lookup, unknown -> unk."""
     ids = [C2I.get(c, UNK) for c in string]

@@ -11,7 +11,7 @@ struct ParamOff {
   long fc_w, fc_b, total;
 };
 
-static inline int vpad(const pg_dims* d) { return 64; }
+static inline int vpad(const pg_dims* d) { return PG_VPAD(d->V); }
 // encoder shape (vae_model.py:63-81); 0 / 0 in pg_dims = one layer, one direction
 static inline int enc_layers(const pg_dims* d) { return d->Lq > 0 ? d->Lq : 1; }
 static inline int enc_dirs(const pg_dims* d) { return d->qbidir ? 2 : 1; }

@@ -148,8 +148,8 @@ static __global__ void reparam_bwd_kernel(const float* __restrict__ mulv, const 
   dq_op[o] = from_f32<T>(dmu); dq_op[o + Dz] = from_f32<T>(dlv);
 }
 
-// ---- cross entropy: one wave per packed row (V <= 64) ------------------------------------------------
-template <typename T>
+// ---- cross entropy: one wave per packed row; lane k holds vocabulary entries k and (NV = 2: Vp = 128) k + 64 -----------
+template <typename T, int NV>
 static __global__ void ce_kernel(const float* __restrict__ logits, const int* __restrict__ tgt, long N, int V, int Vp, int pad,
                           T* __restrict__ dlogits, float* __restrict__ scal) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -157,17 +157,36 @@ static __global__ void ce_kernel(const float* __restrict__ logits, const int* __
   float loss = 0.0f, cnt = 0.0f;
   // grid-stride over rows, one wave per row: few blocks => few atomics on the two loss words
   for (long r = (long)blockIdx.x * nw + wv; r < N; r += (long)gridDim.x * nw) {
-    const float x = lane < V ? logits[r * Vp + lane] : -INFINITY;
-    const float mx = wave_max(x);
-    const float e = lane < V ? __expf(x - mx) : 0.0f;
-    const float s = wave_sum(e);
+    float x[NV], e[NV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = lane + 64 * i;
+      x[i] = v < V ? logits[r * Vp + v] : -INFINITY;
+      mx = fmaxf(mx, x[i]);
+    }
+    mx = wave_max(mx);
+    float se = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      e[i] = lane + 64 * i < V ? __expf(x[i] - mx) : 0.0f;
+      se += e[i];
+    }
+    const float s = wave_sum(se);
     const int tg = tgt[r];
     const bool w = tg != pad;
-    const float xt = __shfl(x, tg < 64 ? tg : 0, 64);
+    float xt = __shfl(x[0], tg & 63, 64);
+    if (NV > 1) {
+      const float x1 = __shfl(x[NV - 1], tg & 63, 64);
+      xt = tg >= 64 ? x1 : xt;
+    }
     if (w) { loss += __logf(s) + mx - xt; cnt += 1.0f; }
-    if (dlogits && lane < Vp) {
-      const float p = e / s;
-      dlogits[r * Vp + lane] = from_f32<T>(w && lane < V ? p - (lane == tg ? 1.0f : 0.0f) : 0.0f);
+    if (dlogits) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int v = lane + 64 * i;
+        if (v < Vp) dlogits[r * Vp + v] = from_f32<T>(w && v < V ? e[i] / s - (v == tg ? 1.0f : 0.0f) : 0.0f);
+      }
     }
   }
   __shared__ float pl[16], pc[16];

@@ -48,7 +48,8 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void sample_head_kernel(const typena
   RowSrc<T> as{htop, H, m0, n};
   RowSrc<T> bs{fcw, H, 0, Cfg::BN};
   mma_mainloop_nt<Cfg, Cfg::TN, 0>(acc, as, bs, H, smem);
-  float* sl = reinterpret_cast<float*>(smem);  // [BM][65]
+  constexpr int LDY = Cfg::BN + 1;             // BN = the padded vocabulary width (64 or 128)
+  float* sl = reinterpret_cast<float*>(smem);  // [BM][LDY]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
 #pragma unroll
@@ -57,12 +58,12 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void sample_head_kernel(const typena
     for (int tn = 0; tn < Cfg::TN; ++tn)
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg)
-        sl[Cfg::row_of(wm, tm, reg, lane) * 65 + Cfg::col_in_group(wn, tn, lane & 31)] = acc[tm][tn][reg];
+        sl[Cfg::row_of(wm, tm, reg, lane) * LDY + Cfg::col_in_group(wn, tn, lane & 31)] = acc[tm][tn][reg];
   __syncthreads();
   const int row = threadIdx.x;
   const int b = m0 + row;
   if (row >= Cfg::BM || b >= n) return;
-  float* y = sl + row * 65;
+  float* y = sl + row * LDY;
   float mx = -INFINITY;
   int amax = 0;
   for (int v = 0; v < V; ++v) {
@@ -86,8 +87,8 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void sample_head_kernel(const typena
       u = pg_u01(r.x);
     }
     if (probs_out) {   // parity hook: the probabilities the draw sees
-      float* po = probs_out + ((long)(step - 1) * n + b) * 64;
-      for (int v = 0; v < 64; ++v) po[v] = v < V ? y[v] / s : 0.0f;
+      float* po = probs_out + ((long)(step - 1) * n + b) * Cfg::BN;
+      for (int v = 0; v < Cfg::BN; ++v) po[v] = v < V ? y[v] / s : 0.0f;
     }
     float cdf = 0.0f;
     w = V - 1;
@@ -171,7 +172,7 @@ static int sample_t(const pg_dims* d, int dtype, const float* params, const void
         pa.forced = forced ? forced + r0 * max_len : nullptr;
         const bool no_compact = getenv("PG_SAMPLE_NO_COMPACT") != nullptr;   // A/B aid, read per call
         pa.compact = (forced || no_compact) ? 0 : 1;
-        pa.probs_out = probs_out ? probs_out + r0 * 64 : nullptr; pa.p_stride = n;
+        pa.probs_out = probs_out ? probs_out + r0 * 64 : nullptr; pa.p_stride = n;   // (V <= 64 here: dec_sample_persist_supported)
         pa.sync = at<unsigned>(ws, w.sync);
         PG_TRY(launch_dec_sample_persist(pa, st));
       }
@@ -179,7 +180,9 @@ static int sample_t(const pg_dims* d, int dtype, const float* params, const void
     }
   }
   using HCfg = TileCfg<T, 128, 64, 8, 4, 1>;
-  static_assert(HCfg::SMEM_BYTES >= 128 * 65 * 4, "head kernel LDS too small for the logits tile");
+  using HCfg2 = TileCfg<T, 128, 128, 8, 4, 1>;   // V in (64, 128]
+  static_assert(HCfg::SMEM_BYTES >= 128 * 65 * 4 && HCfg2::SMEM_BYTES >= 128 * 129 * 4, "head kernel LDS too small for the logits tile");
+  const bool wide = vpad(d) == 128;
   for (int i = 1; i < max_len; ++i) {
     const int p = (i - 1) & 1;
     for (int l = 0; l < L; ++l) {
@@ -205,10 +208,16 @@ static int sample_t(const pg_dims* d, int dtype, const float* params, const void
       a.h32 = at<float>(ws, w.carry[l]);
       PG_TRY(launch_gru_fwd<T>(a, st));
     }
-    PG_LAUNCH_BIG_SMEM(sample_head_kernel<HCfg>, dim3(cdiv(n, HCfg::BM)), dim3(HCfg::NTHREADS), HCfg::SMEM_BYTES, st,
-                       at<T>(ws, w.hop[L - 1][p ^ 1]), n, Hd, at<T>(shadow, so.fc_w), at<float>(shadow, so.fc_b), d->V,
-                       1.0f / temp, uniforms, (unsigned long long)seed, row_offset, i, multinomial, d->eos, max_len, tokens,
-                       end_pads, at<int>(ws, w.tok), at<int>(ws, w.eos), forced, probs_out);
+    if (!wide)
+      PG_LAUNCH_BIG_SMEM(sample_head_kernel<HCfg>, dim3(cdiv(n, HCfg::BM)), dim3(HCfg::NTHREADS), HCfg::SMEM_BYTES, st,
+                         at<T>(ws, w.hop[L - 1][p ^ 1]), n, Hd, at<T>(shadow, so.fc_w), at<float>(shadow, so.fc_b), d->V,
+                         1.0f / temp, uniforms, (unsigned long long)seed, row_offset, i, multinomial, d->eos, max_len, tokens,
+                         end_pads, at<int>(ws, w.tok), at<int>(ws, w.eos), forced, probs_out);
+    else
+      PG_LAUNCH_BIG_SMEM(sample_head_kernel<HCfg2>, dim3(cdiv(n, HCfg2::BM)), dim3(HCfg2::NTHREADS), HCfg2::SMEM_BYTES, st,
+                         at<T>(ws, w.hop[L - 1][p ^ 1]), n, Hd, at<T>(shadow, so.fc_w), at<float>(shadow, so.fc_b), d->V,
+                         1.0f / temp, uniforms, (unsigned long long)seed, row_offset, i, multinomial, d->eos, max_len, tokens,
+                         end_pads, at<int>(ws, w.tok), at<int>(ws, w.eos), forced, probs_out);
     PG_CHECK_LAUNCH();
   }
   return PG_OK;

@@ -641,8 +641,12 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
       e.bias = at<float>(shadow, so.fc_b); e.C32 = at<float>(ws, w.d_logits); e.ldc = Vp;
       PG_TRY(launch_gemm_nt<T>(at<T>(ws, w.d_hseq[L - 1]), Hd, at<T>(shadow, so.fc_w), Hd, (int)Nd, Vp, Hd, e, st));
     }
-    hipLaunchKernelGGL(ce_kernel<T>, dim3(std::min<int>(cdiv(Nd, 4), 1024)), dim3(256), 0, st, at<float>(ws, w.d_logits), at<int>(ws, w.dec_tgt), Nd,
-                       d->V, Vp, d->pad, save ? at<T>(ws, w.d_dlogits) : (T*)nullptr, scal);
+    if (Vp == 64)
+      hipLaunchKernelGGL((ce_kernel<T, 1>), dim3(std::min<int>(cdiv(Nd, 4), 1024)), dim3(256), 0, st, at<float>(ws, w.d_logits),
+                         at<int>(ws, w.dec_tgt), Nd, d->V, Vp, d->pad, save ? at<T>(ws, w.d_dlogits) : (T*)nullptr, scal);
+    else   // V in (64, 128]: two vocabulary entries per lane
+      hipLaunchKernelGGL((ce_kernel<T, 2>), dim3(std::min<int>(cdiv(Nd, 4), 1024)), dim3(256), 0, st, at<float>(ws, w.d_logits),
+                         at<int>(ws, w.dec_tgt), Nd, d->V, Vp, d->pad, save ? at<T>(ws, w.d_dlogits) : (T*)nullptr, scal);
     PG_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(finalize_ce_kernel, dim3(1), dim3(1), 0, st, scal, dp ? dp->ce_count : 0.0f, recon);

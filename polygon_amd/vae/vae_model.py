@@ -197,6 +197,11 @@ class _Engine:
         m = self.model
         return 1 + 4 * int(m.q_n_layers) * (2 if m.q_bidir else 1) + 4
 
+    @property
+    def vpad(self):
+        """PG_VPAD(V) of include/polygon_hip.h: width of the logits / probability rows the library writes."""
+        return 64 if self.dims.V <= 64 else 128
+
     def q_dropout(self):
         """nn.GRU's inter-layer dropout of the encoder (vae_model.py:69): train mode and more than one layer only."""
         m = self.model
@@ -471,10 +476,11 @@ class _DecoderFn(torch.autograd.Function):
         ctx.eng, ctx.batch, ctx.ws = eng, batch, ws
         ctx.cfg = (p_drop, seed, all_steps)
         if want_logits:
-            # packed [rows, 64] fp32 logits live inside the workspace: expose them as a tensor view of it
+            # packed [rows, Vp] fp32 logits live inside the workspace: expose them as a tensor view of it
             n = batch.n_tokens if all_steps else batch.n_tokens - B
             off = logits_ptr - ws.data_ptr()
-            logits = ws[off:off + n * 64 * 4].view(torch.float32).view(n, 64).clone()
+            vp = eng.vpad
+            logits = ws[off:off + n * vp * 4].view(torch.float32).view(n, vp).clone()
         else:
             logits = torch.empty(0, device=dev)
         ctx.mark_non_differentiable(logits)
@@ -711,7 +717,7 @@ class VAE(nn.Module):
         """Token matrix of ``sample``: (tokens uint8 [n, max_len], end_pads int32 [n]) on the device.
         ``uniforms`` [max_len-1, n] pins the inverse-CDF draws (parity mode); otherwise Philox(seed, row, step).
         Parity hooks (pg_sample_forced): ``forced`` uint8 [n, max_len] teacher-forces the token fed to every step;
-        ``return_probs`` adds the per-step probabilities float [max_len-1, n, 64] as a third result."""
+        ``return_probs`` adds the per-step probabilities float [max_len-1, n, 64 or 128 (V > 64)] as a third result."""
         eng = self._engine
         with torch.no_grad():
             eng.ensure_shadow()
@@ -742,7 +748,7 @@ class VAE(nn.Module):
             hooks = forced is not None or return_probs
             if hooks and n_batch > CH:
                 raise RuntimeError("the parity hooks (forced / return_probs) take at most %d rows" % CH)
-            probs = torch.zeros(max_len - 1, n_batch, 64, device=dev) if return_probs else None
+            probs = torch.zeros(max_len - 1, n_batch, eng.vpad, device=dev) if return_probs else None
             if forced is not None:
                 forced = forced.to(dev, torch.uint8).contiguous()
                 if tuple(forced.shape) != (n_batch, max_len):

@@ -173,6 +173,8 @@ def test_batches_above_the_persistent_row_limit_run_as_micro_batches(generic):
         ms, launches, flop, seg = ctypes.c_double(), ctypes.c_long(), ctypes.c_double(), ctypes.c_int()
         _lib.check(L.pg_profile_read(0, ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(flop), ctypes.byref(seg)), "profile")
         assert (seg.value, launches.value) == (3, 3), (seg.value, launches.value)      # three one-launch forward recurrences
+        _lib.check(L.pg_profile_read(1, ctypes.byref(ms), ctypes.byref(launches), ctypes.byref(flop), ctypes.byref(seg)), "profile")
+        assert (seg.value, launches.value) == (3, 3), (seg.value, launches.value)      # ... and three one-launch BPTTs
     finally:
         L.pg_profile_enable(0)
     got = opt.flat_grad.clone()

@@ -121,6 +121,47 @@ def test_train_step_matches_reference(golden_dir, tag, dims, seed, full):
         np.testing.assert_allclose(got, ref, rtol=1e-3, atol=2e-5, err_msg=k)
 
 
+def test_wide_vocabulary_matches_reference(golden_dir):
+    """A data-derived vocabulary of 96 symbols (OneHotVocab.from_data, vae_model.py:9-20; above the 64 one wave lane each
+    covers): tokeniser ids, forward, every gradient, the 3-step trajectory and the sampler's strings of the REAL
+    reference (oracle/make_golden.py wide_vocab_fixture)."""
+    g = np.load(os.path.join(golden_dir, "train_wide.npz"))
+    alphabet = [str(c) for c in g["alphabet"]]
+    with O.vocabulary(alphabet):
+        assert O.ALL_SYMS == alphabet and O.N_VOCAB == 96
+        assert [O.BOS, O.EOS, O.PAD, O.UNK] == g["specials"].tolist()
+        seqs = O.collate([str(s) for s in g["strings"]])
+        assert [len(s) for s in seqs] == g["lens"].tolist()
+        for i, s in enumerate(seqs):
+            assert s.tolist() == g["ids"][i, :len(s)].tolist()
+        P = {k: v.astype(np.float64) for k, v in O.init_params(seed=21, V=96, **TINY).items()}
+        eps = g["eps"].astype(np.float64)
+        enc, dec = O.vae_forward(P, seqs, eps[0])
+        np.testing.assert_allclose(enc["z"], g["z"], rtol=2e-4, atol=2e-5)
+        assert enc["kl"] == pytest.approx(float(g["kl"]), rel=1e-5) and dec["recon"] == pytest.approx(float(g["recon"]), rel=1e-5)
+        np.testing.assert_allclose(dec["y"], g["y"], rtol=1e-3, atol=1e-4)
+        G, _ = O.vae_backward(P, enc, dec, g_kl=float(g["kl_w"]), g_recon=1.0)
+        for k in P:
+            ref = g["grad/" + k]
+            np.testing.assert_allclose(G[k], ref, rtol=1e-3, atol=1e-6 + 1e-4 * np.abs(ref).max(), err_msg=k)
+        P0 = {k: v.copy() for k, v in P.items()}
+        st = O.adam_state(P)
+        for s in range(len(g["losses"])):
+            enc, dec = O.vae_forward(P, seqs, eps[s])
+            G, _ = O.vae_backward(P, enc, dec, g_kl=float(g["kl_w"]), g_recon=1.0)
+            G, total = O.clip_grad_norm(G, 50.0)
+            assert total == pytest.approx(g["gnorms"][s], rel=1e-3)
+            P = O.adam_step(P, G, st, lr=3e-4)
+        for k in P:
+            np.testing.assert_allclose(P[k], g["pfinal/" + k], rtol=1e-3, atol=2e-5, err_msg=k)
+        ml = int(g["sample_max_len"])
+        x, ep = O.sample_tokens(P0, g["sample_z"].astype(np.float64), g["sample_u"], max_len=ml)
+        assert O.tokens_to_strings(x, ep) == [str(s) for s in g["sample_strings"]]
+        x, ep = O.sample_tokens(P0, g["sample_z"].astype(np.float64), None, max_len=ml, multinomial=False)
+        assert O.tokens_to_strings(x, ep) == [str(s) for s in g["sample_strings_argmax"]]
+    assert O.N_VOCAB == 51 and O.PAD == 49
+
+
 @pytest.mark.parametrize("tag,dims,seed", [("tiny", TINY, 3), ("real", REAL, 4), ("real_t07", REAL, 5)])
 def test_sampler_matches_reference(golden_dir, tag, dims, seed):
     g = np.load(os.path.join(golden_dir, "sample_%s.npz" % tag))
