@@ -145,6 +145,13 @@ PG_API int pg_encoder_gen_bwd(const pg_dims* d, int dtype, const float* params, 
 PG_API int pg_clip_adam(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int step, float lr,
                         float beta1, float beta2, float eps, float max_norm, float* scratch, float* gnorm, void* stream);
 
+/* pg_clip_adam that leaves `grads` ZEROED (no counterpart in the reference, whose loop calls optimizer.zero_grad() before
+ * the next backward, vae_trainer.py:133): the Adam kernel writes the zeros behind its read of each value - also when it
+ * skips the update because a persistent kernel gave up - so the next step's gradient accumulation (the entry points above
+ * add into `grads`) starts from a clean buffer without a separate fill on the step's critical path. */
+PG_API int pg_clip_adam_zero(long n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, int step, float lr,
+                             float beta1, float beta2, float eps, float max_norm, float* scratch, float* gnorm, void* stream);
+
 /* pg_clip_adam for callers that cannot allocate or carry a workspace (code under HIP graph capture, tight serving /
  * fine-tuning loops, harnesses that forbid hipMalloc).  NO counterpart in the reference.  Same arithmetic and kernels as
  * pg_clip_adam; the partial sums of squares live in a library-owned static device array (PG_SUMSQ partials, 2 KiB per GPU,

@@ -186,9 +186,8 @@ int encgen_fwd_t(const pg_dims* d, int dtype, const float* params, void* ws, siz
                        static_cast<char*>(ws), tab);
     PG_CHECK_LAUNCH();
     for (int r = 0; r < nd; ++r) {
-      hipLaunchKernelGGL(gi_table_kernel, dim3(cdiv(3 * H, 256), V), dim3(256), 0, st, params + po.x_emb, E, params + po.g_wih[0][r],
-                         E, params + po.g_bih[0][r], params + po.g_bhh[0][r], H, at<float>(ws, w.table[r]));
-      PG_CHECK_LAUNCH();
+      PG_TRY(launch_gi_table(params + po.x_emb, E, params + po.g_wih[0][r], E, params + po.g_bih[0][r], params + po.g_bhh[0][r], H, V,
+                             at<float>(ws, w.table[r]), st));
       for (int l = 1; l < Lq; ++l) {
         hipLaunchKernelGGL(bias_fold_kernel, dim3(cdiv(3 * H, 256)), dim3(256), 0, st, params + po.g_bih[l][r],
                            params + po.g_bhh[l][r], H, at<float>(ws, w.bias[l][r]));

@@ -46,16 +46,56 @@ template <typename T> __global__ void copy_table_kernel(const float* __restrict_
 }
 
 // tab[v, g] = sum_e emb[v,e] * Wih[g, e] + b_ih[g] + (g < 2H ? b_hh[g] : 0)
-static __global__ void gi_table_kernel(const float* __restrict__ emb, int E, const float* __restrict__ Wih, int ldw,
-                                const float* __restrict__ bih, const float* __restrict__ bhh, int H, float* __restrict__ tab) {
-  const int v = blockIdx.y;
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+// Block = 64 gate columns x a slice of the vocabulary: the 64 W_ih rows (read with consecutive threads on consecutive
+// elements of a row) and the embedding rows go through LDS once; a thread then owns one column and walks its vocabulary
+// rows with the W row in a conflict-free padded LDS line.  (First version: one thread per output with both operands read
+// from global memory in a 51-step dependent chain, 16 us on the step's critical path in front of the encoder forward.)
+#define PG_GI_TAB_COLS 64
+#define PG_GI_TAB_VB 16
+static __global__ __launch_bounds__(256) void gi_table_kernel(const float* __restrict__ emb, int E, const float* __restrict__ Wih,
+                                                               int ldw, const float* __restrict__ bih, const float* __restrict__ bhh,
+                                                               int H, int V, float* __restrict__ tab) {
+  extern __shared__ float gts[];             // [64][LD] W rows (LD odd: conflict-free columns), then [PG_GI_TAB_VB][E] embedding rows
+  const int LD = E | 1;
+  float* sW = gts;
+  float* sE = gts + PG_GI_TAB_COLS * LD;
+  const int g0 = blockIdx.x * PG_GI_TAB_COLS, v0 = blockIdx.y * PG_GI_TAB_VB;
+  for (int i = threadIdx.x; i < PG_GI_TAB_COLS * E; i += blockDim.x) {
+    const int r = i / E, k = i % E;
+    sW[r * LD + k] = g0 + r < 3 * H ? Wih[(long)(g0 + r) * ldw + k] : 0.0f;
+  }
+  for (int i = threadIdx.x; i < PG_GI_TAB_VB * E; i += blockDim.x) {
+    const int r = i / E, k = i % E;
+    sE[i] = v0 + r < V ? emb[(long)(v0 + r) * E + k] : 0.0f;
+  }
+  __syncthreads();
+  const int c = threadIdx.x & 63, vq = threadIdx.x >> 6;     // column, quarter of the vocabulary slice
+  const int g = g0 + c;
   if (g >= 3 * H) return;
-  float s = bih[g] + (g < 2 * H ? bhh[g] : 0.0f);
-  const float* e = emb + (long)v * E;
-  const float* w = Wih + (long)g * ldw;
-  for (int k = 0; k < E; ++k) s = fmaf(e[k], w[k], s);
-  tab[(long)v * 3 * H + g] = s;
+  const float bias = bih[g] + (g < 2 * H ? bhh[g] : 0.0f);
+  const float* w = sW + c * LD;
+#pragma unroll
+  for (int j = 0; j < PG_GI_TAB_VB / 4; ++j) {
+    const int vl = vq * (PG_GI_TAB_VB / 4) + j;
+    if (v0 + vl >= V) break;
+    const float* e = sE + vl * E;
+    float s0 = bias, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int k = 0;
+    for (; k + 4 <= E; k += 4) {
+      s0 = fmaf(e[k], w[k], s0); s1 = fmaf(e[k + 1], w[k + 1], s1);
+      s2 = fmaf(e[k + 2], w[k + 2], s2); s3 = fmaf(e[k + 3], w[k + 3], s3);
+    }
+    for (; k < E; ++k) s0 = fmaf(e[k], w[k], s0);
+    tab[(long)(v0 + vl) * 3 * H + g] = (s0 + s1) + (s2 + s3);
+  }
+}
+static inline int launch_gi_table(const float* emb, int E, const float* Wih, int ldw, const float* bih, const float* bhh, int H,
+                                  int V, float* tab, hipStream_t st) {
+  const size_t smem = ((size_t)PG_GI_TAB_COLS * (E | 1) + (size_t)PG_GI_TAB_VB * E) * sizeof(float);   // E <= 256: <= 82 KB
+  PG_LAUNCH_BIG_SMEM(gi_table_kernel, dim3((3 * H + PG_GI_TAB_COLS - 1) / PG_GI_TAB_COLS, (V + PG_GI_TAB_VB - 1) / PG_GI_TAB_VB),
+                     dim3(256), smem, st, emb, E, Wih, ldw, bih, bhh, H, V, tab);
+  PG_CHECK_LAUNCH();
+  return PG_OK;
 }
 static __global__ void bias_fold_kernel(const float* __restrict__ bih, const float* __restrict__ bhh, int H, float* __restrict__ out) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -311,13 +351,18 @@ static __global__ void sumsq_kernel(const float* __restrict__ g, long n, float* 
     partial[blockIdx.x] = a;
   }
 }
+// zero_g (pg_clip_adam_zero): the gradient buffer is left zeroed, on both paths, so that the next step need not fill it
 static __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             long n, const float* __restrict__ partial, int npartial, float max_norm, float step_size,
                             float beta1, float beta2, float inv_sqrt_bc2, float eps, float* __restrict__ gnorm_out,
-                            const unsigned* __restrict__ fail) {
+                            const unsigned* __restrict__ fail, float* __restrict__ zero_g) {
   // a persistent recurrence kernel of this step gave up (sticky device word): its gradients are garbage, so the update is
   // skipped here, on the device, with no host round trip; the host reports the failure at its next check
-  if (fail && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+  if (fail && __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+    if (zero_g)
+      for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) zero_g[i] = 0.0f;
+    return;
+  }
   __shared__ float red[256];
   float s = 0.0f;
   for (int i = threadIdx.x; i < npartial; i += blockDim.x) s += partial[i];
@@ -337,5 +382,6 @@ static __global__ void adam_kernel(float* __restrict__ p, const float* __restric
     const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
     m[i] = mi; v[i] = vi;
     p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    if (zero_g) zero_g[i] = 0.0f;
   }
 }

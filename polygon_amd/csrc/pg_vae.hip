@@ -138,16 +138,14 @@ static int prepare_weights_t(const pg_dims* d, int dtype, const float* params, v
     hipLaunchKernelGGL(copy_table_kernel<T>, dim3(std::min<int>(cdiv(maxel[0], 256), 256), tabs[0].n), dim3(256), 0, st_main, params,
                        static_cast<char*>(shadow), tabs[0]);
     PG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gi_table_kernel, dim3(cdiv(3 * Hq, 256), V), dim3(256), 0, st_main, params + po.x_emb, E, params + po.enc_wih,
-                       E, params + po.enc_bih, params + po.enc_bhh, Hq, at<float>(shadow, so.tab_enc));
-    PG_CHECK_LAUNCH();
+    PG_TRY(launch_gi_table(params + po.x_emb, E, params + po.enc_wih, E, params + po.enc_bih, params + po.enc_bhh, Hq, V,
+                           at<float>(shadow, so.tab_enc), st_main));
   }
   hipLaunchKernelGGL(copy_table_kernel<T>, dim3(std::min<int>(cdiv(maxel[1], 256), 256), tabs[1].n), dim3(256), 0, sd, params,
                      static_cast<char*>(shadow), tabs[1]);
   PG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gi_table_kernel, dim3(cdiv(3 * Hd, 256), V), dim3(256), 0, sd, params + po.x_emb, E, params + po.dec_wih[0],
-                     E + Dz, params + po.dec_bih[0], params + po.dec_bhh[0], Hd, at<float>(shadow, so.tab_dec));
-  PG_CHECK_LAUNCH();
+  PG_TRY(launch_gi_table(params + po.x_emb, E, params + po.dec_wih[0], E + Dz, params + po.dec_bih[0], params + po.dec_bhh[0], Hd, V,
+                         at<float>(shadow, so.tab_dec), sd));
   for (int l = 1; l < d->L; ++l) {
     hipLaunchKernelGGL(bias_fold_kernel, dim3(cdiv(3 * Hd, 256)), dim3(256), 0, sd, params + po.dec_bih[l], params + po.dec_bhh[l],
                        Hd, at<float>(shadow, so.bias_gi[l]));
@@ -981,20 +979,31 @@ extern "C" int pg_encoder_bwd(const pg_dims* d, int dtype, const float* params, 
 // ===================================================================================================
 // optimiser
 // ===================================================================================================
-extern "C" int pg_clip_adam(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int step, float lr,
-                            float beta1, float beta2, float eps, float max_norm, float* scratch, float* gnorm, void* stream) {
-  PG_REQUIRE(n > 0 && params && grads && exp_avg && exp_avg_sq && scratch, "pg_clip_adam: NULL buffer");
-  PG_REQUIRE(step >= 1, "pg_clip_adam: step must be >= 1");
+static int clip_adam_impl(long n, float* params, const float* grads, float* zero_g, float* exp_avg, float* exp_avg_sq, int step,
+                          float lr, float beta1, float beta2, float eps, float max_norm, float* scratch, float* gnorm,
+                          hipStream_t st, const char* who) {
+  PG_REQUIRE(n > 0 && params && grads && exp_avg && exp_avg_sq && scratch, "%s: NULL buffer", who);
+  PG_REQUIRE(step >= 1, "%s: step must be >= 1", who);
   PG_TRY(check_persist());
-  hipStream_t st = (hipStream_t)stream;
   PG_TRY(defer_join(st, true));
   hipLaunchKernelGGL(sumsq_kernel, dim3(PG_SUMSQ_BLOCKS), dim3(256), 0, st, grads, n, scratch);
   PG_CHECK_LAUNCH();
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, n, scratch,
-                     (int)PG_SUMSQ_BLOCKS, max_norm, (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps, gnorm, persist_fail_dev_or_null());
+                     (int)PG_SUMSQ_BLOCKS, max_norm, (float)(lr / bc1), beta1, beta2, (float)(1.0 / sqrt(bc2)), eps, gnorm,
+                     persist_fail_dev_or_null(), zero_g);
   PG_CHECK_LAUNCH();
   return PG_OK;
+}
+extern "C" int pg_clip_adam(long n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int step, float lr,
+                            float beta1, float beta2, float eps, float max_norm, float* scratch, float* gnorm, void* stream) {
+  return clip_adam_impl(n, params, grads, nullptr, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, max_norm, scratch, gnorm,
+                        (hipStream_t)stream, "pg_clip_adam");
+}
+extern "C" int pg_clip_adam_zero(long n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, int step, float lr,
+                                 float beta1, float beta2, float eps, float max_norm, float* scratch, float* gnorm, void* stream) {
+  return clip_adam_impl(n, params, grads, grads, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, max_norm, scratch, gnorm,
+                        (hipStream_t)stream, "pg_clip_adam_zero");
 }
 
 // ---- parity hook: the inter-layer dropout masks of pg_decoder_fwd / pg_decoder_bwd, computed on the HOST by the very

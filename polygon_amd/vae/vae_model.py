@@ -375,7 +375,11 @@ class _Engine:
         if ews is None:
             ews = ws
         if zero:
-            grads.zero_()
+            # FusedClipAdam.step (pg_clip_adam_zero) leaves its buffer zeroed on the stream it ran on: nothing to fill then
+            clean = getattr(self, "clean_grads", None)
+            if clean != (grads.data_ptr(), torch.cuda.current_stream(dev).cuda_stream):
+                grads.zero_()
+        self.clean_grads = None        # dirtied from here on
         self.encoder_fwd(ews, batch, eps, dp, 1, z, None, None, scal[0:1], q_drop, q_seed)
         self.decoder_fwd(ws, batch, z, dp, p_drop, seed, 0, 1, scal[1:2])
         # the decoder's large weight-gradient GEMMs run on the library's side stream, beside the dz chain and the encoder

@@ -58,12 +58,15 @@ class FusedClipAdam(torch.optim.Optimizer):
             self.flat_grad[a:b].zero_()
         g = self.param_groups[0]
         self.n_steps += 1
-        _lib.check(_lib.lib().pg_clip_adam(ctypes.c_long(flat.numel()), _lib.ptr(flat), _lib.ptr(self.flat_grad),
-                                           _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), self.n_steps,
-                                           ctypes.c_float(g['lr']), ctypes.c_float(g['betas'][0]),
-                                           ctypes.c_float(g['betas'][1]), ctypes.c_float(g['eps']),
-                                           ctypes.c_float(self.clip_grad if self.clip_grad else 0.0), _lib.ptr(self.scratch),
-                                           _lib.ptr(self.gnorm), _lib.stream_ptr()), "pg_clip_adam")
+        # pg_clip_adam_zero: the kernel leaves flat_grad zeroed (the reference's zero_grad(), vae_trainer.py:133, folded into
+        # the update), and the engine is told so that the next fused step skips its own fill of the buffer
+        _lib.check(_lib.lib().pg_clip_adam_zero(ctypes.c_long(flat.numel()), _lib.ptr(flat), _lib.ptr(self.flat_grad),
+                                                _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), self.n_steps,
+                                                ctypes.c_float(g['lr']), ctypes.c_float(g['betas'][0]),
+                                                ctypes.c_float(g['betas'][1]), ctypes.c_float(g['eps']),
+                                                ctypes.c_float(self.clip_grad if self.clip_grad else 0.0), _lib.ptr(self.scratch),
+                                                _lib.ptr(self.gnorm), _lib.stream_ptr()), "pg_clip_adam_zero")
+        eng.clean_grads = (self.flat_grad.data_ptr(), torch.cuda.current_stream(flat.device).cuda_stream)
         eng.invalidate()
 
     # ---- optimiser state for checkpoint / resume (no counterpart in the reference, which saves weights only:
