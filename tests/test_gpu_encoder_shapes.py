@@ -154,3 +154,26 @@ def test_encode_in_eval_mode_matches_oracle(dt):
     ref = np.empty_like(enc["mu"])
     ref[order] = enc["mu"]
     assert rel_err(mu, ref) <= TOL[dt]
+
+
+def test_cli_train_with_encoder_flags(tmp_path):
+    """`polygon train --q_bidir --q_n_layers 2 --q_dropout 0.25` (run.py:354-365 of the reference): the CLI builds the model,
+    the fused trainer runs the generic encoder with its dropout, the loss goes down and the checkpoint reloads into a
+    model of the same shape (nn.GRU's key list) and encodes."""
+    from polygon_amd import run
+    from polygon_amd.utils.utils import load_model
+    from polygon_amd.vae.vae_model import VAE
+    data = tmp_path / "train.smiles"
+    data.write_text("\n".join(O.synthetic_smiles(256, seed=18)) + "\n")
+    ckpt = tmp_path / "enc.pt"
+    run.main(["train", "--train_data", str(data), "--model_save", str(ckpt), "--n_epoch", "3", "--n_batch", "64",
+              "--device", "cuda:0", "--compute_dtype", "bf16", "--log_file", str(tmp_path / "log.csv"), "--q_bidir",
+              "--q_n_layers", "2", "--q_dropout", "0.25", "--q_d_h", "128", "--kl_start", "0", "--kl_w_start", "0.0",
+              "--kl_w_end", "0.05", "--quiet"])
+    rows = [l.strip().split(",") for l in open(tmp_path / "log.csv") if l.strip().endswith("Train")]
+    assert len(rows) == 3 and float(rows[2][4]) < float(rows[0][4])
+    model = load_model(VAE, str(ckpt), "cuda:0", model_params=dict(compute_dtype="bf16", q_bidir=True, q_n_layers=2, q_d_h=128))
+    keys = list(model.state_dict().keys())
+    assert "encoder_rnn.weight_hh_l1_reverse" in keys and model.q_mu.in_features == 256
+    mu = model.encode_smiles(["CCO", "c1ccccc1", "C"])
+    assert tuple(mu.shape) == (3, 128) and torch.isfinite(mu).all()
