@@ -103,6 +103,34 @@ __device__ __forceinline__ bool persist_map(int bid, int NG, int NCU, int& g, in
 // 16-row tile j of group g at step t owns slot sv_tile_slot(...) of 16 x H elements, laid out [slice 8][wave 4][lane 64][4].
 // Tiles of step t start at floor(off[t] / 16) + (NG + 1) * t, which leaves room for every group's partial last tile:
 // at most N / 16 + (NG + 1) * T + 1 slots.
+// The two arrival counters a step waits for, polled AT ONCE: lane 0 the first, lane 1 the second.  One after the other the
+// second poll costs an L2 round trip of its own (0.4-0.6 us under load) even when its counter has long been there.  Called
+// by a whole wave; the result is wave-uniform.  Bounded like the single poll (pg_persist_dec.hip, protocol): the lane that
+// runs out of polls sets the launch's error word and the sticky give-up word.
+__device__ __forceinline__ bool pg_wait_ge2(unsigned* p0, unsigned t0, unsigned* p1, unsigned t1, bool two, unsigned* err,
+                                            unsigned* sticky, unsigned limit) {
+  const int lane = threadIdx.x & 63;
+  unsigned* p = lane == 0 ? p0 : p1;
+  const unsigned target = lane == 0 ? t0 : t1;
+  bool pending = lane == 0 || (two && lane == 1);
+  for (unsigned spins = 0;; ++spins) {
+    if (pending) pending = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target;
+    if (__ballot(pending) == 0ull) return true;
+    if ((spins & 63u) == 63u) {
+      const unsigned e = lane == 0 ? __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      if (__ballot(e != 0u) != 0ull) return false;
+    }
+    if (spins > limit) {
+      if (lane == 0) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
 __device__ __forceinline__ long sv_tile_slot(int off_t, int t, int NG, int j, int g) {
   return (long)(off_t >> 4) + (long)(NG + 1) * t + (long)j * NG + g;
 }

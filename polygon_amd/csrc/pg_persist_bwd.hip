@@ -269,9 +269,8 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
     constexpr bool fin = PH == 2;
     PG_STAMP(0);
     // ---- wait for dGH_{l,t+1} (own layer) and dGI_{l+1,t} (layer above)
-    if (tid == 0) {
-      bool ok = wait_ge(cnt_own, (unsigned)(NCU * s), err, a.fail, a.spin_limit);
-      if (has_up && ok) ok = wait_ge(cnt_up, (unsigned)(NCU * (s + 1)), err, a.fail, a.spin_limit);
+    if (wave == 0) {   // (wave-uniform) both counters polled at once: pg_wait_ge2
+      const bool ok = pg_wait_ge2(cnt_own, (unsigned)(NCU * s), cnt_up, (unsigned)(NCU * (s + 1)), has_up, err, a.fail, a.spin_limit);
       PG_STAMP(1);
       // No agent acquire (buffer_inv sc1, 0.7-1.2 us per step) here: everything another workgroup publishes is read with
       // sc1 loads (LDS-DMA included), which are served by L2 and never by this CU's vector cache; the other loads of the
@@ -279,7 +278,7 @@ __device__ __forceinline__ void dec_bwd_body(const DecBwdPersist& a, const Sched
       // (vmcnt(0) below), the barrier orders the other waves' loads behind it, and loads return in issue order.
       if constexpr (AUXL == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // plain payload loads need it
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      *sFlag = ok ? 1u : 0u;
+      if (lane == 0) *sFlag = ok ? 1u : 0u;
     }
     __syncthreads();
     if (*sFlag == 0u) return false;   // block-uniform: somebody gave up

@@ -252,11 +252,10 @@ __device__ __forceinline__ void fwd8_wave(const DecFwdPersist& a, const Sched& s
   for (int t = 0; t < Tg; ++t) {
     PG8_STEP_STAMP(0);
     if constexpr (HS) {
-      if (tid == 0) {
-        bool ok = wait_ge8(cnt_own, (unsigned)(NCU * t), err, a.fail, a.spin_limit);
-        if (!L0 && ok) ok = wait_ge8(cnt_low, (unsigned)(NCU * (t + 1)), err, a.fail, a.spin_limit);
+      if (wave == 0) {   // (wave-uniform) own layer's step t-1 and the lower layer's step t, both counters polled at once
+        const bool ok = pg_wait_ge2(cnt_own, (unsigned)(NCU * t), cnt_low, (unsigned)(NCU * (t + 1)), !L0, err, a.fail, a.spin_limit);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        *sFlag = ok ? 1u : 0u;
+        if (lane == 0) *sFlag = ok ? 1u : 0u;
       }
     }
     const int o = sd.off[t], Bt = sd.off[t + 1] - o;
