@@ -262,11 +262,9 @@ int encgen_fwd_t(const pg_dims* d, int dtype, const float* params, void* ws, siz
   GemmEpi<T> e;
   e.bias = at<float>(ws, w.bq); e.C32 = at<float>(ws, w.mulv); e.ldc = 2 * Dz;
   PG_TRY(launch_gemm_nt<T>(at<T>(ws, w.hfin_op), Hd, at<T>(ws, w.wq), Hd, B, 2 * Dz, Hd, e, st));
-  hipLaunchKernelGGL(reparam_kl_kernel<T>, dim3(cdiv((long)B * Dz, 256)), dim3(256), 0, st, at<float>(ws, w.mulv), eps, B, Dz, z,
-                     (T*)nullptr, mu, logvar, save ? at<float>(ws, w.eps) : (float*)nullptr, scal + SC_KL_SUM);
-  PG_CHECK_LAUNCH();
   const float inv_B = (dp && dp->kl_inv_batch > 0.0f) ? dp->kl_inv_batch : 1.0f / (float)B;
-  hipLaunchKernelGGL(finalize_kl_kernel, dim3(1), dim3(1), 0, st, scal, inv_B, kl);
+  hipLaunchKernelGGL(reparam_kl_kernel<T>, dim3(std::min(cdiv((long)B * Dz, 256), 64)), dim3(256), 0, st, at<float>(ws, w.mulv), eps, B, Dz, z,
+                     (T*)nullptr, mu, logvar, save ? at<float>(ws, w.eps) : (float*)nullptr, scal + SC_KL_SUM, inv_B, kl);
   PG_CHECK_LAUNCH();
   return PG_OK;
 }
@@ -286,12 +284,10 @@ int encgen_bwd_t(const pg_dims* d, int dtype, const float* params, void* ws, siz
   if (Lq == 1) p_drop = 0.0f;
   float* scal = at<float>(ws, w.scalars);
   const float inv_B = (dp && dp->kl_inv_batch > 0.0f) ? dp->kl_inv_batch : 1.0f / (float)B;
-  hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, st, scal, (int)SC_GS_KL, g_host, g_dev, -1, inv_B);
-  PG_CHECK_LAUNCH();
   float* dq = at<float>(ws, w.dq);
   T* dq_op = at<T>(ws, w.dq_op);
   hipLaunchKernelGGL(reparam_bwd_kernel<T>, dim3(cdiv((long)B * Dz, 256)), dim3(256), 0, st, at<float>(ws, w.mulv),
-                     at<float>(ws, w.eps), dz, scal, B, Dz, dq, dq_op);
+                     at<float>(ws, w.eps), dz, g_host * inv_B, g_dev, B, Dz, dq, dq_op);
   PG_CHECK_LAUNCH();
   const T* hfin = at<T>(ws, w.hfin_op);
   PG_TRY(launch_gemm_tn<T>(dq_op, 2 * Dz, hfin, Hd, Dz, Hd, B, grads + po.qmu_w, Hd, 1.0f, nullptr, st, grads + po.qmu_b));

@@ -132,7 +132,9 @@ static inline int make_sched(const int32_t* lens, int B, int Tmax, int drop_last
 }
 
 // ---- training workspace ------------------------------------------------------------------------
-enum { SC_CE_SUM = 0, SC_CE_CNT, SC_KL_SUM, SC_KL, SC_RECON, SC_INV_CNT, SC_GS_CE, SC_GS_KL, SC_N = 16 };
+// (SC_CE_TICKET follows the two CE sums and SC_KL follows SC_KL_SUM: each group is zeroed by ONE memset, and the kernels'
+// last block - told by the ticket; SC_KL itself serves as the KL ticket until that block overwrites it - finalises the loss)
+enum { SC_CE_SUM = 0, SC_CE_CNT, SC_CE_TICKET, SC_KL_SUM, SC_KL, SC_RECON, SC_INV_CNT, SC_GS_CE, SC_GS_KL, SC_N = 16 };
 
 struct TrainWs {
   // int32 arrays

@@ -141,13 +141,18 @@ template <typename T> __global__ void convert_kernel(const float* __restrict__ i
 }
 
 // ---- encoder head: reparameterisation + KL (vae_model.py:232-236) ---------------------------------
+// The block whose ticket is the last one finalises the loss (kl = sum / B_global -> scal[SC_KL], *kl_out): no one-thread
+// kernel behind this one on the step's critical path.  A block's sum has been performed when its atomic has RETURNED
+// (the returned value is consumed before the ticket is drawn), so the last ticket holder reads the complete sum.
 template <typename T>
 static __global__ void reparam_kl_kernel(const float* __restrict__ mulv, const float* __restrict__ eps, int B, int Dz,
                                   float* __restrict__ z, T* __restrict__ z_op, float* __restrict__ mu_out,
-                                  float* __restrict__ lv_out, float* __restrict__ eps_save, float* __restrict__ kl_sum) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+                                  float* __restrict__ lv_out, float* __restrict__ eps_save, float* __restrict__ kl_sum,
+                                  float inv_B, float* __restrict__ kl_out) {
+  // grid-stride over the B x Dz elements: few blocks, because every block ends in two atomics on ONE address (~12 ns each,
+  // serialised at L2: 512 blocks of 256 elements spent 12 us there)
   float term = 0.0f;
-  if (i < (long)B * Dz) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)B * Dz; i += (long)gridDim.x * blockDim.x) {
     const int b = (int)(i / Dz), k = (int)(i % Dz);
     const float mu = mulv[(long)b * 2 * Dz + k], lv = mulv[(long)b * 2 * Dz + Dz + k];
     const float e = eps ? eps[i] : 0.0f;
@@ -157,7 +162,7 @@ static __global__ void reparam_kl_kernel(const float* __restrict__ mulv, const f
     if (mu_out) mu_out[i] = mu;
     if (lv_out) lv_out[i] = lv;
     if (eps_save) eps_save[i] = e;
-    term = 0.5f * (__expf(lv) + mu * mu - 1.0f - lv);
+    term += 0.5f * (__expf(lv) + mu * mu - 1.0f - lv);
   }
   term = wave_sum(term);
   __shared__ float part[16];
@@ -167,18 +172,26 @@ static __global__ void reparam_kl_kernel(const float* __restrict__ mulv, const f
   if (threadIdx.x == 0) {
     float s = 0.0f;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += part[w];
-    atomicAdd(kl_sum, s);
+    const float before = atomicAdd(kl_sum, s);
+    unsigned* ticket = reinterpret_cast<unsigned*>(kl_sum + 1);      // SC_KL: zeroed with SC_KL_SUM, overwritten below
+    asm volatile("" ::"v"(before) : "memory");                       // the returned value is waited for: the sum is in place
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+      const float kl = atomicAdd(kl_sum, 0.0f) * inv_B;
+      kl_sum[1] = kl;
+      if (kl_out) *kl_out = kl;
+    }
   }
 }
 
 // dq[b, 0:Dz] = dmu, dq[b, Dz:2Dz] = dlogvar
 template <typename T>
 static __global__ void reparam_bwd_kernel(const float* __restrict__ mulv, const float* __restrict__ eps, const float* __restrict__ dz,
-                                   const float* __restrict__ scal, int B, int Dz, float* __restrict__ dq, T* __restrict__ dq_op) {
+                                   float s_host, const float* __restrict__ g_dev, int B, int Dz, float* __restrict__ dq,
+                                   T* __restrict__ dq_op) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)B * Dz) return;
   const int b = (int)(i / Dz), k = (int)(i % Dz);
-  const float s_kl = scal[SC_GS_KL];
+  const float s_kl = s_host * (g_dev ? *g_dev : 1.0f);   // upstream gradient of kl x 1 / B_global
   const float mu = mulv[(long)b * 2 * Dz + k], lv = mulv[(long)b * 2 * Dz + Dz + k];
   const float g = dz ? dz[i] : 0.0f;
   const float dmu = g + s_kl * mu;
@@ -240,9 +253,19 @@ static __global__ void ce_kernel(const float* __restrict__ logits, const int* __
   }
 }
 
-static __global__ void finalize_kl_kernel(float* scal, float inv_B, float* kl_out) {
-  scal[SC_KL] = scal[SC_KL_SUM] * inv_B;
-  if (kl_out) *kl_out = scal[SC_KL];
+// the block that draws the last CE ticket finalises (fused kernel); the plain path keeps the one-thread kernel below
+__device__ __forceinline__ void ce_add_and_finalize(float* scal, float loss, float cnt, unsigned nblocks, float count_override,
+                                                    float* recon_out) {
+  const float b0 = atomicAdd(scal + SC_CE_SUM, loss);
+  const float b1 = atomicAdd(scal + SC_CE_CNT, cnt);
+  asm volatile("" ::"v"(b0), "v"(b1) : "memory");                      // the returned values are waited for: both sums are in place
+  if (atomicAdd(reinterpret_cast<unsigned*>(scal + SC_CE_TICKET), 1u) == nblocks - 1) {
+    const float sum = atomicAdd(scal + SC_CE_SUM, 0.0f);
+    const float c = count_override > 0.0f ? count_override : atomicAdd(scal + SC_CE_CNT, 0.0f);
+    scal[SC_INV_CNT] = 1.0f / c;
+    scal[SC_RECON] = sum / c;
+    if (recon_out) *recon_out = sum / c;
+  }
 }
 static __global__ void finalize_ce_kernel(float* scal, float count_override, float* recon_out) {
   const float cnt = count_override > 0.0f ? count_override : scal[SC_CE_CNT];

@@ -406,11 +406,9 @@ static int encoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
   GemmEpi<T> e;
   e.bias = at<float>(shadow, so.bq); e.C32 = at<float>(ws, w.e_mulv); e.ldc = 2 * Dz;
   PG_TRY(launch_gemm_nt<T>(at<T>(ws, w.e_hfin_op), Hq, at<T>(shadow, so.wq), Hq, B, 2 * Dz, Hq, e, st));
-  hipLaunchKernelGGL(reparam_kl_kernel<T>, dim3(cdiv((long)B * Dz, 256)), dim3(256), 0, st, at<float>(ws, w.e_mulv), eps, B, Dz, z,
-                     at<T>(ws, w.e_zop), mu, logvar, save ? at<float>(ws, w.e_eps) : (float*)nullptr, scal + SC_KL_SUM);
-  PG_CHECK_LAUNCH();
   const float inv_B = (dp && dp->kl_inv_batch > 0.0f) ? dp->kl_inv_batch : 1.0f / (float)B;
-  hipLaunchKernelGGL(finalize_kl_kernel, dim3(1), dim3(1), 0, st, scal, inv_B, kl);
+  hipLaunchKernelGGL(reparam_kl_kernel<T>, dim3(std::min(cdiv((long)B * Dz, 256), 64)), dim3(256), 0, st, at<float>(ws, w.e_mulv), eps, B, Dz, z,
+                     at<T>(ws, w.e_zop), mu, logvar, save ? at<float>(ws, w.e_eps) : (float*)nullptr, scal + SC_KL_SUM, inv_B, kl);
   PG_CHECK_LAUNCH();
   return PG_OK;
 }
@@ -446,7 +444,8 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void fc_ce_kernel(const typename Cfg
                                                                const float* __restrict__ fcb, int V, int Vp,
                                                                const int* __restrict__ tgt, int pad,
                                                                float* __restrict__ logits, typename Cfg::T* __restrict__ dlogits,
-                                                               float* __restrict__ scal) {
+                                                               float* __restrict__ scal, float count_override,
+                                                               float* __restrict__ recon_out) {
   using T = typename Cfg::T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int m0 = blockIdx.x * Cfg::BM;
@@ -504,8 +503,7 @@ __global__ __launch_bounds__(Cfg::NTHREADS) void fc_ce_kernel(const typename Cfg
   if (threadIdx.x == 0) {
     float a = 0.0f, c = 0.0f;
     for (int w = 0; w < NW; ++w) { a += sl[w]; c += sl[16 + w]; }
-    atomicAdd(scal + SC_CE_SUM, a);
-    atomicAdd(scal + SC_CE_CNT, c);
+    ce_add_and_finalize(scal, a, c, gridDim.x, count_override, recon_out);
   }
 }
 
@@ -529,7 +527,7 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
                      at<int>(ws, w.dec_off), save ? at<T>(ws, w.b_onehot) : (T*)nullptr, Vp);
   PG_CHECK_LAUNCH();
   float* scal = at<float>(ws, w.scalars);
-  PG_CHECK_HIP(hipMemsetAsync(scal + SC_CE_SUM, 0, 2 * sizeof(float), st));
+  PG_CHECK_HIP(hipMemsetAsync(scal + SC_CE_SUM, 0, 3 * sizeof(float), st));   // the two sums and the ticket
   T* z_op = at<T>(ws, w.d_zop);
   PG_TRY(convert_to<T>(z, z_op, (long)B * Dz, st));
   {  // per-sequence half of the layer-0 input projection: W_ih0[:, E:] z
@@ -631,7 +629,7 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
     PG_LAUNCH_BIG_SMEM(fc_ce_kernel<FCfg>, dim3(cdiv(Nd, FCfg::BM)), dim3(FCfg::NTHREADS), FCfg::SMEM_BYTES, st,
                        at<T>(ws, w.d_hseq[L - 1]), Nd, Hd, at<T>(shadow, so.fc_w), at<float>(shadow, so.fc_b), d->V, Vp,
                        at<int>(ws, w.dec_tgt), d->pad, logits_packed ? at<float>(ws, w.d_logits) : (float*)nullptr,   // logits only when the caller takes them
-                       save ? at<T>(ws, w.d_dlogits) : (T*)nullptr, scal);
+                       save ? at<T>(ws, w.d_dlogits) : (T*)nullptr, scal, dp ? dp->ce_count : 0.0f, recon);   // (its last block finalises the loss)
     PG_CHECK_LAUNCH();
   } else {
     {  // vocab projection
@@ -646,9 +644,9 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
       hipLaunchKernelGGL((ce_kernel<T, 2>), dim3(std::min<int>(cdiv(Nd, 4), 1024)), dim3(256), 0, st, at<float>(ws, w.d_logits),
                          at<int>(ws, w.dec_tgt), Nd, d->V, Vp, d->pad, save ? at<T>(ws, w.d_dlogits) : (T*)nullptr, scal);
     PG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(finalize_ce_kernel, dim3(1), dim3(1), 0, st, scal, dp ? dp->ce_count : 0.0f, recon);
+    PG_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(finalize_ce_kernel, dim3(1), dim3(1), 0, st, scal, dp ? dp->ce_count : 0.0f, recon);
-  PG_CHECK_LAUNCH();
   if (logits_packed) *logits_packed = at<float>(ws, w.d_logits);
   return PG_OK;
 }
@@ -685,16 +683,21 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   const int Hd = d->Hd, Dz = d->Dz, L = d->L, Vp = vpad(d), V = d->V, E = d->E;
   const int b_mul = dp ? dp->b_mul : 1, b_add = dp ? dp->b_add : 0;
   float* scal = at<float>(ws, w.scalars);
+  // scale of the CE gradients = upstream gradient / count: with a host-side upstream gradient (the fused step) the GEMMs
+  // take g_host as alpha and 1 / count straight from the forward pass's slot - no one-thread kernel on the critical path
+  const bool gs_fold = g_dev == nullptr;
+  const float a_ce = gs_fold ? g_host : 1.0f;
+  if (!gs_fold)
   hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, st, scal, (int)SC_GS_CE, g_host, g_dev, (int)SC_INV_CNT, 1.0f);
   PG_CHECK_LAUNCH();
-  const float* s_ce = scal + SC_GS_CE;
+  const float* s_ce = scal + (gs_fold ? SC_INV_CNT : SC_GS_CE);
   T* dlog = at<T>(ws, w.d_dlogits);
   const T* top = at<T>(ws, w.d_hseq[L - 1]);
   // (decoder_fc's weight gradient is enqueued with the other weight gradients, behind the recurrence)
   float* dout = at<float>(ws, w.b_dout);
   {
     GemmEpi<T> e;
-    e.C32 = dout; e.ldc = Hd; e.alpha_dev = s_ce;
+    e.C32 = dout; e.ldc = Hd; e.alpha = a_ce; e.alpha_dev = s_ce;
     PG_TRY(launch_gemm_nt<T>(dlog, Vp, at<T>(shadow, so.fc_wT), Vp, (int)Nd, Hd, Vp, e, st));
   }
   float* dh0 = at<float>(ws, w.b_dh0);
@@ -814,7 +817,7 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   auto big_stream = [&]() { which = (two && (nbig++ & 1)) ? 1 : 0; return which ? g_side2 : sg_big; };
   const bool slabs = !getenv("PG_TN_ATOMIC");
   hipStream_t sg = sg_big;
-  PG_TRY(launch_gemm_tn<T>(dlog, Vp, top, Hd, V, Hd, (int)Nd, grads + po.fc_w, Hd, 1.0f, s_ce, sg, grads + po.fc_b));   // decoder_fc
+  PG_TRY(launch_gemm_tn<T>(dlog, Vp, top, Hd, V, Hd, (int)Nd, grads + po.fc_w, Hd, a_ce, s_ce, sg, grads + po.fc_b));   // decoder_fc
   for (int l = L - 1; l >= 0; --l) {
     T* dGI = at<T>(ws, w.b_dGI_l[l]);
     T* dGH = at<T>(ws, w.b_dGH_l[l]);
@@ -893,12 +896,10 @@ static int encoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   const int Hq = d->Hq, Dz = d->Dz, Vp = vpad(d), V = d->V, E = d->E;
   float* scal = at<float>(ws, w.scalars);
   const float inv_B = (dp && dp->kl_inv_batch > 0.0f) ? dp->kl_inv_batch : 1.0f / (float)B;
-  hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1), 0, st, scal, (int)SC_GS_KL, g_host, g_dev, -1, inv_B);
-  PG_CHECK_LAUNCH();
   float* dq = at<float>(ws, w.b_dq);
   T* dq_op = at<T>(ws, w.b_dq_op);
   hipLaunchKernelGGL(reparam_bwd_kernel<T>, dim3(cdiv((long)B * Dz, 256)), dim3(256), 0, st, at<float>(ws, w.e_mulv),
-                     at<float>(ws, w.e_eps), dz, scal, B, Dz, dq, dq_op);
+                     at<float>(ws, w.e_eps), dz, g_host * inv_B, g_dev, B, Dz, dq, dq_op);
   PG_CHECK_LAUNCH();
   const T* hfin = at<T>(ws, w.e_hfin_op);
   PG_TRY(launch_gemm_tn<T>(dq_op, 2 * Dz, hfin, Hq, Dz, Hq, B, grads + po.qmu_w, Hq, 1.0f, nullptr, st, grads + po.qmu_b));
