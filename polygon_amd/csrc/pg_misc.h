@@ -361,9 +361,16 @@ static __global__ void small_gemm_kernel(const float* __restrict__ A, long sam, 
 // ---- optimiser: global-norm clip + Adam over the flat buffers -----------------------------------------
 #define PG_SUMSQ_BLOCKS 512
 static __global__ void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ partial) {
-  float s = 0.0f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s = fmaf(g[i], g[i], s);
-  s = wave_sum(s);
+  // 16-byte loads, two independent sums per thread (the scalar version read 18 MB at 1.1 TB/s: 16 us behind the join)
+  float s = 0.0f, s2 = 0.0f;
+  const long n4 = ((reinterpret_cast<size_t>(g) & 15) == 0) ? n / 4 : 0;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = g4[i];
+    s = fmaf(v.x, v.x, s); s2 = fmaf(v.y, v.y, s2); s = fmaf(v.z, v.z, s); s2 = fmaf(v.w, v.w, s2);
+  }
+  for (long i = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s = fmaf(g[i], g[i], s);
+  s = wave_sum(s + s2);
   __shared__ float part[16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (lane == 0) part[wv] = s;
