@@ -259,10 +259,16 @@ int encgen_fwd_t(const pg_dims* d, int dtype, const float* params, void* ws, siz
   hipLaunchKernelGGL(enc_concat_final_kernel<T>, dim3(ew_blocks((long)B * Hd)), dim3(256), 0, st, at<float>(ws, w.carry[Lq - 1][0]),
                      at<float>(ws, w.carry[Lq - 1][nd - 1]), B, H, nd, at<T>(ws, w.hfin_op));
   PG_CHECK_LAUNCH();
+  const float inv_B = (dp && dp->kl_inv_batch > 0.0f) ? dp->kl_inv_batch : 1.0f / (float)B;
+  if constexpr (std::is_same<T, bf16_t>::value) {   // heads + reparameterisation + KL as one kernel (pg_heads.hip)
+    int status = PG_OK;
+    if (launch_enc_heads(at<T>(ws, w.hfin_op), B, Hd, at<T>(ws, w.wq), at<float>(ws, w.bq), Dz, eps, at<float>(ws, w.mulv), z, (T*)nullptr,
+                         mu, logvar, save ? at<float>(ws, w.eps) : (float*)nullptr, scal + SC_KL_SUM, inv_B, kl, st, &status))
+      return status;
+  }
   GemmEpi<T> e;
   e.bias = at<float>(ws, w.bq); e.C32 = at<float>(ws, w.mulv); e.ldc = 2 * Dz;
   PG_TRY(launch_gemm_nt<T>(at<T>(ws, w.hfin_op), Hd, at<T>(ws, w.wq), Hd, B, 2 * Dz, Hd, e, st));
-  const float inv_B = (dp && dp->kl_inv_batch > 0.0f) ? dp->kl_inv_batch : 1.0f / (float)B;
   hipLaunchKernelGGL(reparam_kl_kernel<T>, dim3(std::min(cdiv((long)B * Dz, 256), 64)), dim3(256), 0, st, at<float>(ws, w.mulv), eps, B, Dz, z,
                      (T*)nullptr, mu, logvar, save ? at<float>(ws, w.eps) : (float*)nullptr, scal + SC_KL_SUM, inv_B, kl);
   PG_CHECK_LAUNCH();

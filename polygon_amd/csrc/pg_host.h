@@ -39,3 +39,11 @@ static int small_gemm(const float* A, long sam, long sak, const float* Bm, long 
 }
 
 int check_persist();   // pg_vae.hip: sticky give-up word of the persistent kernels -> PG_ERR_* at entry
+
+// pg_heads.hip: the row-local stretches between the recurrences as one kernel each (bf16).  Return false when the shape is
+// not covered (nothing was launched: the caller takes the separate GEMM + element-wise launches); *status = launch result.
+bool launch_enc_heads(const bf16_t* hfin, int B, int K, const bf16_t* wq, const float* bq, int Dz, const float* eps, float* mulv,
+                      float* z, bf16_t* z_op, float* mu_out, float* lv_out, float* eps_save, float* kl_sum, float inv_B,
+                      float* kl_out, hipStream_t st, int* status);
+bool launch_dec_zin(const float* z, int B, int Dz, int Hd, const bf16_t* wih0z, const bf16_t* latw, const float* latb, bf16_t* z_op,
+                    float* zproj, float* h0_32, bf16_t* h0_op, hipStream_t st, int* status);

@@ -403,10 +403,17 @@ static int encoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
   }
   // q_mu | q_logvar on the final states (each row's own last step: the carry is updated in place)
   if (!persist) PG_TRY(convert_to<T>(carry, at<T>(ws, w.e_hfin_op), (long)B * Hq, st));
+  const float inv_B = (dp && dp->kl_inv_batch > 0.0f) ? dp->kl_inv_batch : 1.0f / (float)B;
+  if constexpr (std::is_same<T, bf16_t>::value) {   // heads + reparameterisation + KL as one kernel (pg_heads.hip)
+    int status = PG_OK;
+    if (launch_enc_heads(at<T>(ws, w.e_hfin_op), B, Hq, at<T>(shadow, so.wq), at<float>(shadow, so.bq), Dz, eps, at<float>(ws, w.e_mulv), z,
+                         at<T>(ws, w.e_zop), mu, logvar, save ? at<float>(ws, w.e_eps) : (float*)nullptr, scal + SC_KL_SUM, inv_B, kl, st,
+                         &status))
+      return status;
+  }
   GemmEpi<T> e;
   e.bias = at<float>(shadow, so.bq); e.C32 = at<float>(ws, w.e_mulv); e.ldc = 2 * Dz;
   PG_TRY(launch_gemm_nt<T>(at<T>(ws, w.e_hfin_op), Hq, at<T>(shadow, so.wq), Hq, B, 2 * Dz, Hq, e, st));
-  const float inv_B = (dp && dp->kl_inv_batch > 0.0f) ? dp->kl_inv_batch : 1.0f / (float)B;
   hipLaunchKernelGGL(reparam_kl_kernel<T>, dim3(std::min(cdiv((long)B * Dz, 256), 64)), dim3(256), 0, st, at<float>(ws, w.e_mulv), eps, B, Dz, z,
                      at<T>(ws, w.e_zop), mu, logvar, save ? at<float>(ws, w.e_eps) : (float*)nullptr, scal + SC_KL_SUM, inv_B, kl);
   PG_CHECK_LAUNCH();
@@ -529,16 +536,25 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
   float* scal = at<float>(ws, w.scalars);
   PG_CHECK_HIP(hipMemsetAsync(scal + SC_CE_SUM, 0, 3 * sizeof(float), st));   // the two sums and the ticket
   T* z_op = at<T>(ws, w.d_zop);
-  PG_TRY(convert_to<T>(z, z_op, (long)B * Dz, st));
-  {  // per-sequence half of the layer-0 input projection: W_ih0[:, E:] z
-    GemmEpi<T> e;
-    e.C32 = at<float>(ws, w.d_zproj); e.ldc = 3 * Hd;
-    PG_TRY(launch_gemm_nt<T>(z_op, Dz, at<T>(shadow, so.wih0z), Dz, B, 3 * Hd, Dz, e, st));
+  bool zin_done = false;
+  if constexpr (std::is_same<T, bf16_t>::value) {   // z -> bf16, z projection and h0 as one kernel (pg_heads.hip)
+    int status = PG_OK;
+    zin_done = launch_dec_zin(z, B, Dz, Hd, at<T>(shadow, so.wih0z), at<T>(shadow, so.lat_w), params + po.lat_b, z_op,
+                              at<float>(ws, w.d_zproj), at<float>(ws, w.d_h0_32), at<T>(ws, w.d_h0_op), st, &status);
+    PG_TRY(status);
   }
-  {  // h0 = decoder_lat(z)
-    GemmEpi<T> e;
-    e.bias = params + po.lat_b; e.C32 = at<float>(ws, w.d_h0_32); e.Ct = at<T>(ws, w.d_h0_op); e.ldc = Hd;
-    PG_TRY(launch_gemm_nt<T>(z_op, Dz, at<T>(shadow, so.lat_w), Dz, B, Hd, Dz, e, st));
+  if (!zin_done) {
+    PG_TRY(convert_to<T>(z, z_op, (long)B * Dz, st));
+    {  // per-sequence half of the layer-0 input projection: W_ih0[:, E:] z
+      GemmEpi<T> e;
+      e.C32 = at<float>(ws, w.d_zproj); e.ldc = 3 * Hd;
+      PG_TRY(launch_gemm_nt<T>(z_op, Dz, at<T>(shadow, so.wih0z), Dz, B, 3 * Hd, Dz, e, st));
+    }
+    {  // h0 = decoder_lat(z)
+      GemmEpi<T> e;
+      e.bias = params + po.lat_b; e.C32 = at<float>(ws, w.d_h0_32); e.Ct = at<T>(ws, w.d_h0_op); e.ldc = Hd;
+      PG_TRY(launch_gemm_nt<T>(z_op, Dz, at<T>(shadow, so.lat_w), Dz, B, Hd, Dz, e, st));
+    }
   }
   const bool drop = p_drop > 0.0f;
   const bool persist_dec = std::is_same<T, bf16_t>::value && use_persistent_dec(Hd, L, B);
