@@ -197,7 +197,7 @@ int encgen_fwd_t(const pg_dims* d, int dtype, const float* params, void* ws, siz
   }
   hipLaunchKernelGGL(build_packed_kernel<T>, dim3(se.T, cdiv(B, 256)), dim3(256), 0, st, d_tokens, B, Tmax, d->pad, se, 1,
                      at<int>(ws, w.tok), at<int>(ws, w.tgt), at<int>(ws, w.rt), at<int>(ws, w.rb), (int*)nullptr,
-                     save ? at<T>(ws, w.onehot) : (T*)nullptr, vpad(d));
+                     save ? at<T>(ws, w.onehot) : (T*)nullptr, vpad(d), (unsigned*)nullptr, 0);
   PG_CHECK_LAUNCH();
   float* scal = at<float>(ws, w.scalars);
   PG_CHECK_HIP(hipMemsetAsync(scal + SC_KL_SUM, 0, 2 * sizeof(float), st));

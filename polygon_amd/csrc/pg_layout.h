@@ -140,7 +140,7 @@ struct TrainWs {
   // int32 arrays
   size_t enc_tok, dec_tok, dec_tgt, dec_t, dec_b, dec_off;
   size_t scalars;
-  size_t sync;   // counters of the group-persistent decoder kernels (pg_persist.h), 8256 bytes
+  size_t sync, sync_bwd;   // counters of the group-persistent decoder kernels (pg_persist.h), 8256 bytes each; `scalars` follows
   // encoder
   size_t e_carry, e_hop[2], e_sv[5], e_hfin_op, e_mulv, e_eps, e_zop;
   // decoder forward
@@ -163,8 +163,11 @@ static inline TrainWs train_ws_layout(const pg_dims* d, int dtype, long B, long 
   const size_t Nm = Ne > Nd ? Ne : Nd;
   w.enc_tok = take(Ne * 4); w.dec_tok = take(Nd * 4); w.dec_tgt = take(Nd * 4); w.dec_t = take(Nd * 4);
   w.dec_b = take(Nd * 4); w.dec_off = take((PG_MAX_T + 2) * 4);
+  // the counters of the decoder's two persistent kernels, then the scalars (whose first three words are the CE sums and
+  // their ticket): everything the decoder forward must find zeroed lies in ONE span, cleared by one memset
+  w.sync = take(2064 * 4);   // PG_PERSIST_SYNC_WORDS (pg_persist.h): forward recurrence
+  w.sync_bwd = take(2064 * 4);   // BPTT
   w.scalars = take(SC_N * 4);
-  w.sync = take(2064 * 4);   // PG_PERSIST_SYNC_WORDS (pg_persist.h)
   w.e_carry = take(B * Hq * 4); w.e_hop[0] = take(B * Hq * es); w.e_hop[1] = take(B * Hq * es);
   // r, z, n, hn of the encoder are kept in the persistent kernels' lane-major order, one 16-row slot per (step, block),
   // steps padded by 16 rows (pg_persist.hip): up to 16 * (max steps 512 + 1) rows more than the packed count

@@ -106,13 +106,18 @@ static __global__ void bias_fold_kernel(const float* __restrict__ bih, const flo
 // mode 0: encoder (tok only).  mode 1: decoder (tok, target = next token, t, b) + offsets copy.
 // onehot (optional, [N, Vp], operand precision): row r = unit vector of tok[r] - the left operand of the embedding-table
 // gradient GEMM (one-hot^T . dGI), built here, in the forward pass, so that nothing of it is left for the step's tail
+// zero (optional): n_zero words the pass must find cleared (loss sums, tickets, counters) - written here instead of by a
+// memset of its own in front of the recurrence
 template <typename T>
 static __global__ void build_packed_kernel(const int32_t* __restrict__ tokens, int B, int Tmax, int pad, Sched s, int mode,
                                     int* __restrict__ tok, int* __restrict__ tgt, int* __restrict__ rt, int* __restrict__ rb,
-                                    int* __restrict__ off_out, T* __restrict__ onehot, int Vp) {
+                                    int* __restrict__ off_out, T* __restrict__ onehot, int Vp, unsigned* __restrict__ zero,
+                                    int n_zero) {
   const int t = blockIdx.x;
   if (off_out && blockIdx.x == 0 && blockIdx.y == 0)
     for (int i = threadIdx.x; i <= s.T + 1; i += blockDim.x) off_out[i] = s.off[i];
+  if (zero && blockIdx.x == gridDim.x - 1 && blockIdx.y == 0)   // (the last step's block has the fewest rows to pack)
+    for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero[i] = 0u;
   const int Bt = s.off[t + 1] - s.off[t];
   const int b = blockIdx.y * blockDim.x + threadIdx.x;
   if (b >= Bt) return;

@@ -212,13 +212,18 @@ bool dec_persist_supported(int H, int L, int B);
 // the two-waves-per-SIMD forward kernel of the training configuration (pg_persist_dec8.hip), launched by launch_dec_fwd_persist
 bool dec_fwd8_enabled();
 int launch_dec_fwd8(DecFwdPersist& a, const Sched& sd, int grid, hipStream_t stream);
-int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t stream);
+// host_flags: what the caller has taken over from the launcher, to keep it off the stream's critical path
+constexpr int PG_PERSIST_SYNC_ZEROED = 1;   // a.sync was zeroed by the caller, ordered before this launch
+constexpr int PG_PERSIST_NO_MIRROR = 2;     // the caller mirrors the give-up word to the host itself, later in the step
+int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t stream, int host_flags = 0);
 // runs the whole decoder BPTT recurrence, then dh0_32 / dh0_op [B, H] = sum over layers of the h0 gradients
-int launch_dec_bwd_persist(DecBwdPersist& a, const Sched& sd, int H, float* dh0_32, bf16_t* dh0_op, hipStream_t stream);
+int launch_dec_bwd_persist(DecBwdPersist& a, const Sched& sd, int H, float* dh0_32, bf16_t* dh0_op, hipStream_t stream,
+                           int host_flags = 0);
 // process-wide sticky give-up word of the group-persistent kernels: device address (allocated on first use) and the
 // stream-ordered copy to its pinned host mirror that persist_poll_failure() reads
 int persist_fail_words(unsigned** dev);
 int persist_fail_mirror(hipStream_t stream);
+int persist_fail_refresh();   // blocking read of the device word into the host mirror (no-op before the first persistent launch)
 bool persist_dma_plain();
 unsigned long long* persist_stamps_for(int which);   // development aid: stamp buffer if tracing kernel `which`, else null
 // nonzero once a persistent kernel of this process gave up waiting on another workgroup (checked by every entry point);

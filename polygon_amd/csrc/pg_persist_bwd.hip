@@ -657,7 +657,8 @@ __global__ void dh0_sum_kernel(DecBwdPersist a, long n, float* out32, bf16_t* ou
 
 }  // namespace
 
-int launch_dec_bwd_persist(DecBwdPersist& a, const Sched& sd, int H, float* dh0_32, bf16_t* dh0_op, hipStream_t stream) {
+int launch_dec_bwd_persist(DecBwdPersist& a, const Sched& sd, int H, float* dh0_32, bf16_t* dh0_op, hipStream_t stream,
+                           int host_flags) {
   PG_REQUIRE(dec_persist_supported(H, a.L, a.B), "dec_bwd_persist: shape H=%d L=%d not covered", H, a.L);
   PG_REQUIRE(a.sync && a.dout && dh0_32 && dh0_op, "dec_bwd_persist: NULL buffer");
   for (int l = 0; l < a.L; ++l)
@@ -671,7 +672,8 @@ int launch_dec_bwd_persist(DecBwdPersist& a, const Sched& sd, int H, float* dh0_
   a.spin_limit = persist_spin_limit();
   a.stamps = persist_stamps_for(1);
   a.dbg = getenv("PG_PERSIST_DBG") ? atoi(getenv("PG_PERSIST_DBG")) : 0;
-  PG_CHECK_HIP(hipMemsetAsync(a.sync, 0, PG_PERSIST_SYNC_WORDS * sizeof(unsigned), stream));
+  if (!(host_flags & PG_PERSIST_SYNC_ZEROED))
+    PG_CHECK_HIP(hipMemsetAsync(a.sync, 0, PG_PERSIST_SYNC_WORDS * sizeof(unsigned), stream));
   const bool dbgk = a.dbg != 0 || a.stamps != nullptr;
   const bool plain = persist_dma_plain();
   const bool fast = !dbgk && !plain && a.L >= 2 && a.sv_lane && a.p_drop > 0.0f && !getenv("PG_PERSIST_NO_FAST");
@@ -698,7 +700,7 @@ int launch_dec_bwd_persist(DecBwdPersist& a, const Sched& sd, int H, float* dh0_
   void* kargs[] = {&a, const_cast<Sched*>(&sd)};
   PG_CHECK_HIP(hipLaunchKernel(kern, dim3(grid), dim3(256), kargs, (size_t)SMEM, stream));
   PG_CHECK_LAUNCH();
-  PG_TRY(persist_fail_mirror(stream));
+  if (!(host_flags & PG_PERSIST_NO_MIRROR)) PG_TRY(persist_fail_mirror(stream));
   const long n = (long)a.B * H;
   hipLaunchKernelGGL(dh0_sum_kernel, dim3(cdiv(n, 4 * 256)), dim3(256), 0, stream, a, n, dh0_32, dh0_op);
   PG_CHECK_LAUNCH();

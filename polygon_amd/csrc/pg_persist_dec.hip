@@ -507,7 +507,15 @@ int persist_fail_mirror(hipStream_t stream) {
   return PG_OK;
 }
 
-int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t stream) {
+int persist_fail_refresh() {
+  if (!g_fail_host) return PG_OK;
+  unsigned v = 0;
+  PG_CHECK_HIP(hipMemcpy(&v, g_fail_dev, sizeof(unsigned), hipMemcpyDeviceToHost));
+  if (v) *g_fail_host = (int)v;
+  return PG_OK;
+}
+
+int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t stream, int host_flags) {
   PG_REQUIRE(dec_persist_supported(H, a.L, a.B), "dec_fwd_persist: shape H=%d L=%d not covered", H, a.L);
   PG_REQUIRE(a.sync && a.table && a.tok && a.zproj && a.h0_op && a.h0_32, "dec_fwd_persist: NULL buffer");
   using G = DecGeo<512>;
@@ -516,7 +524,8 @@ int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t
   a.spin_limit = persist_spin_limit();
   a.stamps = g_stamps_which == 0 ? g_stamps : nullptr;
   a.dbg = getenv("PG_PERSIST_DBG") ? atoi(getenv("PG_PERSIST_DBG")) : 0;
-  PG_CHECK_HIP(hipMemsetAsync(a.sync, 0, PG_PERSIST_SYNC_WORDS * sizeof(unsigned), stream));
+  if (!(host_flags & PG_PERSIST_SYNC_ZEROED))
+    PG_CHECK_HIP(hipMemsetAsync(a.sync, 0, PG_PERSIST_SYNC_WORDS * sizeof(unsigned), stream));
   // (PG_FWD8_KO=32, diagnostic builds only: the stamps go to the two-waves-per-SIMD kernel's own instrumented instantiation)
   static const bool stamps8 = getenv("PG_FWD8_KO") && atoi(getenv("PG_FWD8_KO")) == 32;
   const bool dbgk = a.dbg != 0 || (a.stamps != nullptr && !stamps8);
@@ -536,7 +545,7 @@ int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t
   PG_REQUIRE(grid <= n_cu, "dec_fwd_persist: %d workgroups cannot be co-resident on %d CUs", grid, n_cu);
   if (fast && dec_fwd8_enabled()) {   // the training configuration: two waves per SIMD (pg_persist_dec8.hip)
     PG_TRY(launch_dec_fwd8(a, sd, grid, stream));
-    PG_TRY(persist_fail_mirror(stream));
+    if (!(host_flags & PG_PERSIST_NO_MIRROR)) PG_TRY(persist_fail_mirror(stream));
     return PG_OK;
   }
   const void* kern = fast    ? reinterpret_cast<const void*>(dec_fwd_persist_kernel<512, AUX_SC1, false, true>)
@@ -553,7 +562,7 @@ int launch_dec_fwd_persist(DecFwdPersist& a, const Sched& sd, int H, hipStream_t
   void* kargs[] = {&a, const_cast<Sched*>(&sd)};
   PG_CHECK_HIP(hipLaunchKernel(kern, dim3(grid), dim3(256), kargs, (size_t)G::SMEM, stream));
   PG_CHECK_LAUNCH();
-  PG_TRY(persist_fail_mirror(stream));
+  if (!(host_flags & PG_PERSIST_NO_MIRROR)) PG_TRY(persist_fail_mirror(stream));
   return PG_OK;
 }
 

@@ -219,6 +219,7 @@ static int check_persist_now() {
 
 extern "C" int pg_check_failure(void* stream) {
   PG_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  PG_TRY(persist_fail_refresh());   // the device word itself: the asynchronous mirrors are an early warning only
   return check_persist_now();
 }
 
@@ -253,6 +254,22 @@ static hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr, g_ev_join2 = nullptr
 static bool g_defer_pending = false;
 static hipEvent_t g_ev_shadow = nullptr;     // decoder shadows rebuilt on the side stream (pg_prepare_weights)
 static bool g_shadow_pending = false;
+// The batch the encoder forward was given while that rebuild was pending: an event on the caller's stream at the encoder's
+// entry (its tokens are complete there, and nothing earlier on the stream still uses the workspace), which the side stream
+// waits for.  The decoder forward of the SAME tokens and workspace may then put its prologue on the side stream.
+static hipEvent_t g_ev_tok = nullptr;
+static const void* g_tok_ptr = nullptr;
+static const void* g_tok_ws = nullptr;
+static int note_tokens(const void* d_tokens, const void* ws, hipStream_t st) {
+  g_tok_ptr = nullptr;
+  if (!(g_shadow_pending && g_side && !g_defer_pending)) return PG_OK;
+  if (!g_ev_tok) PG_CHECK_HIP(hipEventCreateWithFlags(&g_ev_tok, hipEventDisableTiming));
+  PG_CHECK_HIP(hipEventRecord(g_ev_tok, st));
+  PG_CHECK_HIP(hipStreamWaitEvent(g_side, g_ev_tok, 0));
+  g_tok_ptr = d_tokens;
+  g_tok_ws = ws;
+  return PG_OK;
+}
 extern "C" int pg_defer_weight_grads(int on) {
   const int old = g_defer;
   if (on >= 0) g_defer = on ? 1 : 0;
@@ -334,6 +351,16 @@ static bool use_persistent_dec_bwd(int H, int L, int B) { return !(persist_off_m
 struct SvLayoutRec { const void* ws; int lane; };
 static SvLayoutRec g_sv_layout[64] = {};
 static int g_sv_layout_next = 0;
+// Whether the BPTT counters of a workspace are still as pg_decoder_fwd's prologue zeroed them (set = true), consumed by
+// the first pg_decoder_bwd after it (set = false; returns what it found).  Same stream order as the saved activations.
+static const void* g_bwd_sync_clean[8] = {};
+static bool bwd_sync_record(const void* ws, bool set) {
+  static int next = 0;
+  for (auto& r : g_bwd_sync_clean)
+    if (r == ws) { if (!set) r = nullptr; return true; }
+  if (set) { g_bwd_sync_clean[next] = ws; next = (next + 1) % 8; }
+  return false;
+}
 static void sv_layout_record(const void* ws, int lane) {
   for (auto& r : g_sv_layout)
     if (r.ws == ws) { r.lane = lane; return; }
@@ -361,12 +388,11 @@ static int encoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
   const TrainWs w = train_ws_layout(d, dtype, B, Ne, Ne);
   PG_REQUIRE(ws_bytes >= w.total, "encoder_fwd: workspace too small (%zu < %zu)", ws_bytes, w.total);
   const int Hq = d->Hq, Dz = d->Dz;
+  float* scal = at<float>(ws, w.scalars);
   hipLaunchKernelGGL(build_packed_kernel<T>, dim3(se.T, cdiv(B, 256)), dim3(256), 0, st, d_tokens, B, Tmax, d->pad, se, 0,
                      at<int>(ws, w.enc_tok), (int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr,
-                     save ? at<T>(ws, w.e_onehot) : (T*)nullptr, vpad(d));
+                     save ? at<T>(ws, w.e_onehot) : (T*)nullptr, vpad(d), reinterpret_cast<unsigned*>(scal + SC_KL_SUM), 2);   // (KL sum + ticket)
   PG_CHECK_LAUNCH();
-  float* scal = at<float>(ws, w.scalars);
-  PG_CHECK_HIP(hipMemsetAsync(scal + SC_KL_SUM, 0, 2 * sizeof(float), st));
   float* carry = at<float>(ws, w.e_carry);
   bool persist = false;
   if constexpr (std::is_same<T, bf16_t>::value) {
@@ -429,6 +455,7 @@ extern "C" int pg_encoder_fwd(const pg_dims* d, int dtype, const float* params, 
   PG_REQUIRE(params && shadow && ws && d_tokens && z, "pg_encoder_fwd: NULL buffer");
   PG_REQUIRE(!enc_generic(d), "pg_encoder_fwd serves the one-layer one-direction encoder; Lq=%d qbidir=%d goes to pg_encoder_gen_fwd",
              d->Lq, d->qbidir);
+  PG_TRY(note_tokens(d_tokens, ws, (hipStream_t)stream));
   return dtype == PG_BF16
              ? encoder_fwd_t<bf16_t>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, d_tokens, h_lengths, eps, dp,
                                      save_for_backward, z, mu, logvar, kl, (hipStream_t)stream)
@@ -521,6 +548,8 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
   const ParamOff po = param_offsets(d);
   const ShadowOff so = shadow_offsets(d, dtype);
   Sched sd;
+  // (on an argument error the shadow join is still owed: the early returns below go through it)
+  struct JoinOnExit { hipStream_t s; bool done; ~JoinOnExit() { if (!done) shadow_join(s); } } join_guard{st, false};
   PG_TRY(make_sched(lens, B, Tmax, all_steps ? 0 : 1, &sd));
   PG_REQUIRE(sd.T >= 1, "decoder_fwd: sequences of length 1 have no decoder step");
   const long Ne = sum_len(lens, B), Nd = sd.off[sd.T];
@@ -529,12 +558,28 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
   PG_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "decoder_fwd: dropout %f outside [0,1)", p_drop);
   const int Hd = d->Hd, Dz = d->Dz, L = d->L, Vp = vpad(d);
   const int b_mul = dp ? dp->b_mul : 1, b_add = dp ? dp->b_add : 0;
-  hipLaunchKernelGGL(build_packed_kernel<T>, dim3(sd.T, cdiv(B, 256)), dim3(256), 0, st, d_tokens, B, Tmax, d->pad, sd, 1,
-                     at<int>(ws, w.dec_tok), at<int>(ws, w.dec_tgt), at<int>(ws, w.dec_t), at<int>(ws, w.dec_b),
-                     at<int>(ws, w.dec_off), save ? at<T>(ws, w.b_onehot) : (T*)nullptr, Vp);
-  PG_CHECK_LAUNCH();
+  // The packing of the batch and the zeroing of the loss words need nothing of the encoder: while the decoder's shadow
+  // weights of this step are being rebuilt on the library's side stream (pg_prepare_weights under deferral, beside the
+  // encoder forward), they go there too, behind the shadows, and the caller's stream picks both up with the ONE event wait
+  // it owes anyway - 12 us of launches and a second wait off the stretch between the two forward recurrences.  (Not while
+  // deferred gradient GEMMs of an earlier micro-batch may still read this workspace's one-hot rows: g_defer_pending.)
+  const bool side_pro = g_shadow_pending && g_side && !g_defer_pending && g_tok_ptr == d_tokens && g_tok_ws == ws;
+  g_tok_ptr = nullptr;
+  hipStream_t pro = side_pro ? g_side : st;
+  // zeroed by the same kernel, as ONE span: the counters of the forward recurrence and of this step's BPTT, the two CE sums
+  // and their ticket
   float* scal = at<float>(ws, w.scalars);
-  PG_CHECK_HIP(hipMemsetAsync(scal + SC_CE_SUM, 0, 3 * sizeof(float), st));   // the two sums and the ticket
+  static_assert(SC_CE_SUM == 0 && SC_CE_TICKET == 2, "the CE words lead the scalars");
+  PG_REQUIRE(w.sync < w.sync_bwd && w.sync_bwd < w.scalars && sd.T >= 1, "decoder_fwd: layout of the zeroed span");
+  hipLaunchKernelGGL(build_packed_kernel<T>, dim3(sd.T, cdiv(B, 256)), dim3(256), 0, pro, d_tokens, B, Tmax, d->pad, sd, 1,
+                     at<int>(ws, w.dec_tok), at<int>(ws, w.dec_tgt), at<int>(ws, w.dec_t), at<int>(ws, w.dec_b),
+                     at<int>(ws, w.dec_off), save ? at<T>(ws, w.b_onehot) : (T*)nullptr, Vp, at<unsigned>(ws, w.sync),
+                     (int)((w.scalars - w.sync) / 4 + 3));
+  PG_CHECK_LAUNCH();
+  bwd_sync_record(ws, true);
+  if (pro != st) PG_CHECK_HIP(hipEventRecord(g_ev_shadow, pro));               // (re-recorded behind the prologue)
+  join_guard.done = true;
+  PG_TRY(shadow_join(st));
   T* z_op = at<T>(ws, w.d_zop);
   bool zin_done = false;
   if constexpr (std::is_same<T, bf16_t>::value) {   // z -> bf16, z projection and h0 as one kernel (pg_heads.hip)
@@ -585,7 +630,10 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
       pa.p_drop = p_drop; pa.seed = seed; pa.b_mul = b_mul; pa.b_add = b_add;
       pa.sync = at<unsigned>(ws, w.sync);
       const int pslot = prof_begin(0, st);
-      PG_TRY(launch_dec_fwd_persist(pa, sd, Hd, st));
+      // (counters zeroed by the prologue; the training forward leaves the host mirror of the give-up word to the BPTT of
+      // the same step - the word is sticky, the Adam kernel reads it on the device, pg_check_failure reads it itself)
+      const bool bptt_next = save && pa.sv_lane != 0;
+      PG_TRY(launch_dec_fwd_persist(pa, sd, Hd, st, PG_PERSIST_SYNC_ZEROED | (bptt_next ? PG_PERSIST_NO_MIRROR : 0)));
       if (save) sv_layout_record(ws, pa.sv_lane);   // what the launcher's kernel wrote: 1, or 2 (the two-waves-per-SIMD kernel's order)
       double pflop = 0.0;
       for (int t = 0; t < sd.T; ++t) pflop += 2.0 * sched_B(sd, t) * 3.0 * Hd * (L * Hd + (L - 1) * Hd);
@@ -674,8 +722,7 @@ extern "C" int pg_decoder_fwd(const pg_dims* d, int dtype, const float* params, 
   PG_TRY(check_dims(d, dtype));
   PG_TRY(check_persist());
   PG_REQUIRE(params && shadow && ws && d_tokens && z, "pg_decoder_fwd: NULL buffer");
-  PG_TRY(shadow_join((hipStream_t)stream));
-  return dtype == PG_BF16
+  return dtype == PG_BF16     // (the shadow join sits inside, behind the prologue that may share the side stream)
              ? decoder_fwd_t<bf16_t>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, d_tokens, h_lengths, z, dp, p_drop, seed,
                                      all_steps, save_for_backward, recon, logits_packed, (hipStream_t)stream)
              : decoder_fwd_t<float>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, d_tokens, h_lengths, z, dp, p_drop, seed,
@@ -742,10 +789,13 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
       }
       pa.dout = dout;
       pa.p_drop = p_drop; pa.seed = seed; pa.b_mul = b_mul; pa.b_add = b_add;
-      pa.sync = at<unsigned>(ws, w.sync);
+      pa.sync = at<unsigned>(ws, w.sync_bwd);
       const int ps = prof_begin(1, st);
       pa.sv_lane = sv_lane;   // what the forward pass of this step recorded (not re-derived: the persist mask may have changed)
-      PG_TRY(launch_dec_bwd_persist(pa, sd, Hd, dh0, at<T>(ws, w.b_dh0_op), st));
+      // counters: zeroed by the forward pass of this step unless a BPTT has used them since; mirror: at the end, below
+      const bool clean = bwd_sync_record(ws, false);
+      PG_TRY(launch_dec_bwd_persist(pa, sd, Hd, dh0, at<T>(ws, w.b_dh0_op), st,
+                                    PG_PERSIST_NO_MIRROR | (clean ? PG_PERSIST_SYNC_ZEROED : 0)));
       double pf = 0.0;   // algorithmic flop: dh = dGH_{t+1}.W_hh (+ dGI_{l+1,t}.W_ih_{l+1} below the top layer)
       for (int t = -1; t < sd.T; ++t) {
         const double rin = t + 1 < sd.T ? sched_B(sd, t + 1) : 0, rout = t >= 0 ? sched_B(sd, t) : 0;
@@ -878,6 +928,8 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
     PG_TRY(launch_gemm_tn<T>(dh0_op, Hd, at<T>(ws, w.d_zop), Dz, Hd, Dz, B, grads + po.lat_w, Dz, 1.0f, nullptr, sg,
                              grads + po.lat_b));
   }
+  // the host mirror of the give-up word, behind the stream of large GEMMs (the shorter of the tail's chains)
+  if (persist) PG_TRY(persist_fail_mirror(sg_big));
   PG_TRY(defer_done(sg_big, st));
   return PG_OK;
 }
