@@ -25,7 +25,7 @@
 namespace {
 
 struct EncGenWs {
-  size_t tok, tgt, rt, rb, scalars, onehot, dT;
+  size_t tok, tgt, rt, rb, scalars, dT, slab, slab_bytes;
   size_t whh[PG_MAX_ENC_LAYERS][2], whhT[PG_MAX_ENC_LAYERS][2], wih[PG_MAX_ENC_LAYERS][2], wihT[PG_MAX_ENC_LAYERS][2];
   size_t bias[PG_MAX_ENC_LAYERS][2], table[2];
   size_t out[PG_MAX_ENC_LAYERS][2], sv[PG_MAX_ENC_LAYERS][2][5], carry[PG_MAX_ENC_LAYERS][2];
@@ -46,7 +46,8 @@ EncGenWs encgen_layout(const pg_dims* d, int dtype, long B, long N) {
   const size_t Hd = H * nd;
   w.tok = take(N * 4); w.tgt = take(N * 4); w.rt = take(N * 4); w.rb = take(N * 4);
   w.scalars = take(SC_N * 4);
-  w.onehot = take(N * Vp * es); w.dT = take(Vp * 3 * H * 4);
+  w.dT = take(Vp * 3 * H * 4);
+  w.slab_bytes = tok_scatter_layout(N, 3 * (int)H, (int)Vp).total; w.slab = take(w.slab_bytes);
   for (int l = 0; l < Lq; ++l) {
     const size_t in = enc_in(d, l);
     for (int r = 0; r < nd; ++r) {
@@ -197,7 +198,7 @@ int encgen_fwd_t(const pg_dims* d, int dtype, const float* params, void* ws, siz
   }
   hipLaunchKernelGGL(build_packed_kernel<T>, dim3(se.T, cdiv(B, 256)), dim3(256), 0, st, d_tokens, B, Tmax, d->pad, se, 1,
                      at<int>(ws, w.tok), at<int>(ws, w.tgt), at<int>(ws, w.rt), at<int>(ws, w.rb), (int*)nullptr,
-                     save ? at<T>(ws, w.onehot) : (T*)nullptr, vpad(d), (unsigned*)nullptr, 0);
+                     (unsigned*)nullptr, 0);
   PG_CHECK_LAUNCH();
   float* scal = at<float>(ws, w.scalars);
   PG_CHECK_HIP(hipMemsetAsync(scal + SC_KL_SUM, 0, 2 * sizeof(float), st));
@@ -347,11 +348,10 @@ int encgen_bwd_t(const pg_dims* d, int dtype, const float* params, void* ws, siz
         e.C32 = at<float>(ws, w.dX); e.ldc = in; e.accumulate = r > 0;
         PG_TRY(launch_gemm_nt<T>(dGI, 3 * H, at<T>(ws, w.wihT[l][r]), 3 * H, (int)N, in, 3 * H, e, st));
       } else {
-        // embedding layer: dTable = one-hot^T . dGI, then x_emb and W_ih gradients from the V-row table (as pg_encoder_bwd)
+        // embedding layer: dTable = scatter-sum of dGI by token, then x_emb and W_ih gradients from the V-row table (as pg_encoder_bwd)
         float* dT = at<float>(ws, w.dT);
-        PG_CHECK_HIP(hipMemsetAsync(dT, 0, (size_t)Vp * 3 * H * 4, st));
-        PG_TRY(launch_gemm_tn<T>(at<T>(ws, w.onehot), Vp, dGI, 3 * H, Vp, 3 * H, (int)N, dT, 3 * H, 1.0f, nullptr, st, nullptr,
-                                 grads + po.g_bih[0][r]));
+        PG_TRY(launch_tok_scatter_sum<T>(at<int>(ws, w.tok), dGI, 3 * H, N, 3 * H, Vp, dT, grads + po.g_bih[0][r],
+                                         at<char>(ws, w.slab), w.slab_bytes, st));
         PG_TRY(small_gemm(dT, 3 * H, 1, params + po.g_wih[0][r], E, 1, V, E, 3 * H, grads + po.x_emb, E, d->pad, st));
         PG_TRY(small_gemm(dT, 1, 3 * H, params + po.x_emb, E, 1, 3 * H, E, V, grads + po.g_wih[0][r], E, -1, st));
       }

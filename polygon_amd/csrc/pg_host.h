@@ -32,8 +32,8 @@ static int colsum(const T* X, long R, int C, long ld, float* out, float alpha, c
 }
 static int small_gemm(const float* A, long sam, long sak, const float* Bm, long sbk, long sbn, int M, int N, int K, float* C,
                       long ldc, int skip_row, hipStream_t st) {
-  hipLaunchKernelGGL(small_gemm_kernel, dim3(cdiv((long)M * N, 4)), dim3(256), 0, st, A, sam, sak, Bm, sbk, sbn, M, N, K, C, ldc,
-                     skip_row);
+  hipLaunchKernelGGL(small_gemm_kernel, dim3(cdiv(N, 16), cdiv(M, 16), cdiv(K, PG_SG_KC)), dim3(256), 0, st, A, sam, sak, Bm, sbk,
+                     sbn, M, N, K, C, ldc, skip_row);
   PG_CHECK_LAUNCH();
   return PG_OK;
 }

@@ -148,7 +148,9 @@ struct TrainWs {
   size_t d_sv[PG_MAX_LAYERS][5], d_gi, d_logits, d_dlogits;
   // backward
   size_t b_dGI_l[PG_MAX_LAYERS], b_dGH_l[PG_MAX_LAYERS], b_dhz_l[PG_MAX_LAYERS][2];
-  size_t b_dout, b_dGI, b_dGH, b_dhz[2], b_dh0, b_dh0_op, b_dzproj, b_dzproj_op, b_onehot, b_dT, e_onehot, e_dT, b_dq, b_dq_op, b_dhfin;
+  size_t b_dout, b_dGI, b_dGH, b_dhz[2], b_dh0, b_dh0_op, b_dzproj, b_dzproj_op, b_dT, e_dT, b_dq, b_dq_op, b_dhfin;
+  size_t e_slab;             // the encoder table gradient's partial sums, one row of 3 Hq floats per chunk
+  size_t d_ts[3], e_ts[3];   // rows grouped by token for the embedding-table gradients (pg_scatter.h TokSort: perm, chunks, tokchunk)
   size_t b_slab[2];   // split-K slabs of the large weight-gradient GEMMs, one per side stream (PG_TN_SLAB_BYTES, pg_gemm.h)
   size_t total;
 };
@@ -193,9 +195,13 @@ static inline TrainWs train_ws_layout(const pg_dims* d, int dtype, long B, long 
   }
   w.b_dh0 = take(B * Hd * 4); w.b_dh0_op = take(B * Hd * es);
   w.b_dzproj = take(B * 3 * Hd * 4); w.b_dzproj_op = take(B * 3 * Hd * es);
-  w.b_onehot = take(Nd * Vp * es); w.b_dT = take(Vp * 3 * Hd * 4);
+  w.b_dT = take(Vp * 3 * Hd * 4);
   // the encoder's own copies: its embedding-gradient tail runs beside the decoder's deferred one (pg_vae.hip)
-  w.e_onehot = take(Ne * Vp * es); w.e_dT = take(Vp * 3 * Hq * 4);
+  w.e_dT = take(Vp * 3 * Hq * 4);
+  // (chunk tables: N / 128 + Vp entries of 16 bytes - pg_scatter.h tok_sort_chunks, PG_TS_ROWS = 128, checked in pg_vae.hip)
+  w.d_ts[0] = take(Nd * 4); w.d_ts[1] = take((Nd / 128 + Vp) * 16); w.d_ts[2] = take((Vp + 1) * 4);
+  w.e_ts[0] = take(Ne * 4); w.e_ts[1] = take((Ne / 128 + Vp) * 16); w.e_ts[2] = take((Vp + 1) * 4);
+  w.e_slab = take((Ne / 128 + Vp) * 3 * Hq * 4);
   w.b_dq = take(B * 2 * Dz * 4); w.b_dq_op = take(B * 2 * Dz * es); w.b_dhfin = take(B * Hq * 4);
   w.b_slab[0] = take((size_t)776 * 128 * 128 * 4); w.b_slab[1] = take((size_t)776 * 128 * 128 * 4);
   w.total = p;

@@ -2,6 +2,7 @@
 #pragma once
 #include "pg_common.h"
 #include "pg_layout.h"
+#include "pg_scatter.h"   // the embedding-table gradient (scatter-sum by token)
 
 // ---- wave / block reductions (64-wide waves) ----------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
@@ -104,15 +105,12 @@ static __global__ void bias_fold_kernel(const float* __restrict__ bih, const flo
 
 // ---- packed batch ----------------------------------------------------------------------------------
 // mode 0: encoder (tok only).  mode 1: decoder (tok, target = next token, t, b) + offsets copy.
-// onehot (optional, [N, Vp], operand precision): row r = unit vector of tok[r] - the left operand of the embedding-table
-// gradient GEMM (one-hot^T . dGI), built here, in the forward pass, so that nothing of it is left for the step's tail
 // zero (optional): n_zero words the pass must find cleared (loss sums, tickets, counters) - written here instead of by a
 // memset of its own in front of the recurrence
 template <typename T>
 static __global__ void build_packed_kernel(const int32_t* __restrict__ tokens, int B, int Tmax, int pad, Sched s, int mode,
                                     int* __restrict__ tok, int* __restrict__ tgt, int* __restrict__ rt, int* __restrict__ rb,
-                                    int* __restrict__ off_out, T* __restrict__ onehot, int Vp, unsigned* __restrict__ zero,
-                                    int n_zero) {
+                                    int* __restrict__ off_out, unsigned* __restrict__ zero, int n_zero) {
   const int t = blockIdx.x;
   if (off_out && blockIdx.x == 0 && blockIdx.y == 0)
     for (int i = threadIdx.x; i <= s.T + 1; i += blockDim.x) off_out[i] = s.off[i];
@@ -128,16 +126,6 @@ static __global__ void build_packed_kernel(const int32_t* __restrict__ tokens, i
     tgt[r] = (t + 1 < Tmax) ? tokens[(long)b * Tmax + t + 1] : pad;
     rt[r] = t;
     rb[r] = b;
-  }
-  if (onehot) {   // Vp is a multiple of 16 / sizeof(T) (vpad): whole 16-byte chunks
-    constexpr int EPC = 16 / (int)sizeof(T);
-    uint4* row = reinterpret_cast<uint4*>(onehot + (long)r * Vp);
-    for (int c = 0; c < Vp / EPC; ++c) {
-      T e[EPC];
-#pragma unroll
-      for (int i = 0; i < EPC; ++i) e[i] = from_f32<T>(c * EPC + i == v ? 1.0f : 0.0f);
-      row[c] = *reinterpret_cast<const uint4*>(e);
-    }
   }
 }
 
@@ -349,18 +337,35 @@ static __global__ __launch_bounds__(256) void rowseg_sum_kernel(const T* __restr
   for (int e = 0; e < EPC; ++e) { o[e] = s[e]; oo[e] = from_f32<T>(s[e]); }
 }
 
-// one wave per output element: C[m*ldc + n] += alpha * sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]   (all fp32)
-static __global__ void small_gemm_kernel(const float* __restrict__ A, long sam, long sak, const float* __restrict__ Bm, long sbk,
-                                  long sbn, int M, int N, int K, float* __restrict__ C, long ldc, int skip_row) {
-  const int lane = threadIdx.x & 63;
-  const long w = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (w >= (long)M * N) return;
-  const int m = (int)(w / N), n = (int)(w % N);
-  if (m == skip_row) return;
-  float s = 0.0f;
-  for (int k = lane; k < K; k += 64) s = fmaf(A[m * sam + k * sak], Bm[k * sbk + n * sbn], s);
-  s = wave_sum(s);
-  if (lane == 0) atomicAdd(C + m * ldc + n, s);   // x_emb's gradient is accumulated by two streams at once (pg_vae.hip)
+// C[m*ldc + n] += sum_k A[m*sam + k*sak] * B[k*sbk + n*sbn]   (all fp32; the V-row table gradients -> x_emb / W_ih0)
+// One 16 x 16 output tile and one 64-wide slice of K per block, operands staged in LDS with the loads laid along whichever
+// stride is 1, atomic accumulation (split K; and x_emb's gradient is accumulated by two streams at once, pg_vae.hip).
+// (Was one wave per output element: 46 k waves of 30 products each for W_ih0's gradient, 40 us beside the large GEMMs.)
+#define PG_SG_KC 64
+static __global__ __launch_bounds__(256) void small_gemm_kernel(const float* __restrict__ A, long sam, long sak,
+                                                                const float* __restrict__ Bm, long sbk, long sbn, int M, int N,
+                                                                int K, float* __restrict__ C, long ldc, int skip_row) {
+  __shared__ float sA[16][PG_SG_KC + 1];
+  __shared__ float sB[PG_SG_KC][17];
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16, k0 = blockIdx.z * PG_SG_KC;
+  for (int i = threadIdx.x; i < 16 * PG_SG_KC; i += 256) {
+    const int m = sak == 1 ? i / PG_SG_KC : i % 16, k = sak == 1 ? i % PG_SG_KC : i / 16;
+    sA[m][k] = (m0 + m < M && k0 + k < K) ? A[(m0 + m) * sam + (k0 + k) * sak] : 0.0f;
+  }
+  for (int i = threadIdx.x; i < 16 * PG_SG_KC; i += 256) {
+    const int n = sbn == 1 ? i % 16 : i / PG_SG_KC, k = sbn == 1 ? i / 16 : i % PG_SG_KC;
+    sB[k][n] = (n0 + n < N && k0 + k < K) ? Bm[(k0 + k) * sbk + (n0 + n) * sbn] : 0.0f;
+  }
+  __syncthreads();
+  const int tm = threadIdx.x >> 4, tn = threadIdx.x & 15;
+  float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll 8
+  for (int k = 0; k < PG_SG_KC; k += 2) {
+    s0 = fmaf(sA[tm][k], sB[k][tn], s0);
+    s1 = fmaf(sA[tm][k + 1], sB[k + 1][tn], s1);
+  }
+  const int m = m0 + tm, n = n0 + tn;
+  if (m < M && n < N && m != skip_row) atomicAdd(C + m * ldc + n, s0 + s1);
 }
 
 // ---- optimiser: global-norm clip + Adam over the flat buffers -----------------------------------------

@@ -254,9 +254,10 @@ static hipEvent_t g_ev_fork = nullptr, g_ev_join = nullptr, g_ev_join2 = nullptr
 static bool g_defer_pending = false;
 static hipEvent_t g_ev_shadow = nullptr;     // decoder shadows rebuilt on the side stream (pg_prepare_weights)
 static bool g_shadow_pending = false;
-// The batch the encoder forward was given while that rebuild was pending: an event on the caller's stream at the encoder's
-// entry (its tokens are complete there, and nothing earlier on the stream still uses the workspace), which the side stream
-// waits for.  The decoder forward of the SAME tokens and workspace may then put its prologue on the side stream.
+// The batch the encoder forward was given while that rebuild was pending: an event on the caller's stream behind the
+// encoder's packing kernel (the tokens are complete there, and nothing earlier on the stream still uses the workspace),
+// which the side stream waits for.  The encoder's token sort, and the prologue of the decoder forward of the SAME tokens and
+// workspace, may then run on the side stream.
 static hipEvent_t g_ev_tok = nullptr;
 static const void* g_tok_ptr = nullptr;
 static const void* g_tok_ws = nullptr;
@@ -300,17 +301,33 @@ static int defer_fork(hipStream_t st, hipStream_t* side) {   // *side = stream f
 }
 // the second side stream of the fork just made (the caller's stream itself when not deferring)
 static hipStream_t defer_second(hipStream_t side, hipStream_t st) { return side == st ? st : g_side2; }
+// (A join is not repeated on a stream that has already made it: every wait is a barrier packet on the caller's stream, ~6 us
+// each even when the event has long been signalled, and the step used to end on four of them.  Chaining the two side
+// streams into one event was tried: the encoder's embedding tail on the second then queues behind the first.)
+static hipStream_t g_joined_on = nullptr;
+static bool g_joined = false;   // (the legacy default stream is a null handle: a flag, not a sentinel)
 static int defer_done(hipStream_t side, hipStream_t st) {
   if (side == st) return PG_OK;
   PG_CHECK_HIP(hipEventRecord(g_ev_join, side));
   PG_CHECK_HIP(hipEventRecord(g_ev_join2, g_side2));
   g_defer_pending = true;
+  g_joined = false;
+  return PG_OK;
+}
+// more work was queued on the second side stream since defer_done (the encoder's embedding tail): joins wait for this record
+static int defer_rerecord() {
+  PG_CHECK_HIP(hipEventRecord(g_ev_join2, g_side2));
+  g_joined = false;
   return PG_OK;
 }
 static int defer_join(hipStream_t st, bool clear) {
   if (g_defer_pending) {
-    PG_CHECK_HIP(hipStreamWaitEvent(st, g_ev_join, 0));
-    PG_CHECK_HIP(hipStreamWaitEvent(st, g_ev_join2, 0));
+    if (!(g_joined && g_joined_on == st)) {
+      PG_CHECK_HIP(hipStreamWaitEvent(st, g_ev_join, 0));
+      PG_CHECK_HIP(hipStreamWaitEvent(st, g_ev_join2, 0));
+    }
+    g_joined = true;
+    g_joined_on = st;
     if (clear) g_defer_pending = false;
   }
   return PG_OK;
@@ -361,6 +378,29 @@ static bool bwd_sync_record(const void* ws, bool set) {
   if (set) { g_bwd_sync_clean[next] = ws; next = (next + 1) % 8; }
   return false;
 }
+// Whether the workspace holds the rows grouped by token (pg_scatter.h) for the batch its last forward pass packed: bit 0
+// encoder, bit 1 decoder.  Written by the forward passes (set / clear), read by the backward passes.
+struct TokSortRec { const void* ws; int mask; };
+static TokSortRec g_tok_sorted[8] = {};
+static void tok_sorted_set(const void* ws, int bit, bool on) {
+  static int next = 0;
+  for (auto& r : g_tok_sorted)
+    if (r.ws == ws) { r.mask = on ? (r.mask | bit) : (r.mask & ~bit); return; }
+  if (!on) return;
+  g_tok_sorted[next] = {ws, bit};
+  next = (next + 1) % 8;
+}
+static bool tok_sorted(const void* ws, int bit) {
+  for (auto& r : g_tok_sorted)
+    if (r.ws == ws) return (r.mask & bit) != 0;
+  return false;
+}
+static_assert(PG_TS_ROWS == 128, "TrainWs::d_ts / e_ts are sized for 128-row chunks (pg_layout.h)");
+static TokSort tok_sort_at(void* ws, const size_t (&o)[3]) {
+  TokSort ts;
+  ts.perm = at<int>(ws, o[0]); ts.chunks = at<int4>(ws, o[1]); ts.tokchunk = at<int>(ws, o[2]);
+  return ts;
+}
 static void sv_layout_record(const void* ws, int lane) {
   for (auto& r : g_sv_layout)
     if (r.ws == ws) { r.lane = lane; return; }
@@ -391,8 +431,20 @@ static int encoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
   float* scal = at<float>(ws, w.scalars);
   hipLaunchKernelGGL(build_packed_kernel<T>, dim3(se.T, cdiv(B, 256)), dim3(256), 0, st, d_tokens, B, Tmax, d->pad, se, 0,
                      at<int>(ws, w.enc_tok), (int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr,
-                     save ? at<T>(ws, w.e_onehot) : (T*)nullptr, vpad(d), reinterpret_cast<unsigned*>(scal + SC_KL_SUM), 2);   // (KL sum + ticket)
+                     reinterpret_cast<unsigned*>(scal + SC_KL_SUM), 2);   // (zeroes the KL sum and its ticket)
   PG_CHECK_LAUNCH();
+  // The rows grouped by token, for the embedding-table gradient of the backward pass (pg_scatter.h): one block, needs the
+  // packed tokens only.  Beside the recurrence on the library's side stream while the decoder's shadow rebuild is pending
+  // there (an event behind the packing kernel, which the side stream waits for; the join is the one the decoder forward
+  // owes anyway, re-recorded behind the sort), else in order.
+  PG_TRY(note_tokens(d_tokens, ws, st));
+  const bool sort_now = save && Ne <= tok_sort_max_rows(vpad(d));
+  if (sort_now) {
+    hipStream_t ss = g_tok_ptr ? g_side : st;
+    PG_TRY(launch_tok_sort(at<int>(ws, w.enc_tok), Ne, vpad(d), tok_sort_at(ws, w.e_ts), ss));
+    if (ss != st) PG_CHECK_HIP(hipEventRecord(g_ev_shadow, g_side));
+  }
+  tok_sorted_set(ws, 1, sort_now);
   float* carry = at<float>(ws, w.e_carry);
   bool persist = false;
   if constexpr (std::is_same<T, bf16_t>::value) {
@@ -455,7 +507,6 @@ extern "C" int pg_encoder_fwd(const pg_dims* d, int dtype, const float* params, 
   PG_REQUIRE(params && shadow && ws && d_tokens && z, "pg_encoder_fwd: NULL buffer");
   PG_REQUIRE(!enc_generic(d), "pg_encoder_fwd serves the one-layer one-direction encoder; Lq=%d qbidir=%d goes to pg_encoder_gen_fwd",
              d->Lq, d->qbidir);
-  PG_TRY(note_tokens(d_tokens, ws, (hipStream_t)stream));
   return dtype == PG_BF16
              ? encoder_fwd_t<bf16_t>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, d_tokens, h_lengths, eps, dp,
                                      save_for_backward, z, mu, logvar, kl, (hipStream_t)stream)
@@ -573,10 +624,14 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
   PG_REQUIRE(w.sync < w.sync_bwd && w.sync_bwd < w.scalars && sd.T >= 1, "decoder_fwd: layout of the zeroed span");
   hipLaunchKernelGGL(build_packed_kernel<T>, dim3(sd.T, cdiv(B, 256)), dim3(256), 0, pro, d_tokens, B, Tmax, d->pad, sd, 1,
                      at<int>(ws, w.dec_tok), at<int>(ws, w.dec_tgt), at<int>(ws, w.dec_t), at<int>(ws, w.dec_b),
-                     at<int>(ws, w.dec_off), save ? at<T>(ws, w.b_onehot) : (T*)nullptr, Vp, at<unsigned>(ws, w.sync),
+                     at<int>(ws, w.dec_off), at<unsigned>(ws, w.sync),
                      (int)((w.scalars - w.sync) / 4 + 3));
   PG_CHECK_LAUNCH();
   bwd_sync_record(ws, true);
+  // the rows grouped by token, for the embedding-table gradient of the backward pass: needs the tokens only
+  const bool sort_now = save && Nd <= tok_sort_max_rows(Vp);
+  if (sort_now) PG_TRY(launch_tok_sort(at<int>(ws, w.dec_tok), Nd, Vp, tok_sort_at(ws, w.d_ts), pro));
+  tok_sorted_set(ws, 2, sort_now);
   if (pro != st) PG_CHECK_HIP(hipEventRecord(g_ev_shadow, pro));               // (re-recorded behind the prologue)
   join_guard.done = true;
   PG_TRY(shadow_join(st));
@@ -914,11 +969,16 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   {
     hipStream_t sg = defer_second(sg_big, st);
     // layer 0 input = [x_emb[token] ; z]: token half through the gather table, z half per sequence
-    T* oh = at<T>(ws, w.b_onehot);   // built by the forward pass (build_packed_kernel)
     float* dT = at<float>(ws, w.b_dT);
-    PG_CHECK_HIP(hipMemsetAsync(dT, 0, (size_t)Vp * 3 * Hd * 4, sg));
-    PG_TRY(launch_gemm_tn<T>(oh, Vp, dGI0, 3 * Hd, Vp, 3 * Hd, (int)Nd, dT, 3 * Hd, 1.0f, nullptr, sg, nullptr,
-                             persist ? nullptr : grads + po.dec_bih[0]));
+    // (scratch: the slab buffer of this stream's large GEMMs, which are through in stream order; the rows were grouped by
+    // token in the forward pass when it could)
+    char* scr = at<char>(ws, w.b_slab[sg == sg_big ? 0 : 1]);
+    float* bih0 = persist ? nullptr : grads + po.dec_bih[0];
+    if (tok_sorted(ws, 2))
+      PG_TRY(launch_tok_sum_sorted<T>(dGI0, 3 * Hd, Nd, 3 * Hd, Vp, tok_sort_at(ws, w.d_ts), reinterpret_cast<float*>(scr),
+                                      PG_TN_SLAB_BYTES, dT, bih0, 0, sg));
+    else
+      PG_TRY(launch_tok_scatter_sum<T>(at<int>(ws, w.dec_tok), dGI0, 3 * Hd, Nd, 3 * Hd, Vp, dT, bih0, scr, PG_TN_SLAB_BYTES, sg));
     // d x_emb[v,e] += sum_g dT[v,g] W_ih0[g,e] ; d W_ih0[g,e] += sum_v dT[v,g] x_emb[v,e]
     PG_TRY(small_gemm(dT, 3 * Hd, 1, params + po.dec_wih[0], E + Dz, 1, V, E, 3 * Hd, grads + po.x_emb, E, d->pad, sg));
     PG_TRY(small_gemm(dT, 1, 3 * Hd, params + po.x_emb, E, 1, 3 * Hd, E, V, grads + po.dec_wih[0], E + Dz, -1, sg));
@@ -1012,19 +1072,35 @@ static int encoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   // the second side stream, beside the W_hh gradient below, instead of queueing behind it on the caller's stream.  Own
   // one-hot / table-gradient scratch and atomic accumulation into x_emb's gradient: the decoder's deferred tail may still
   // be running there.
+  // (PG_ENC_TAIL_INORDER=1, A/B aid: everything on the caller's stream, the table gradient in front of the W_hh gradient -
+  // measured 0.02 ms per step slower.)
+  static const bool tail_side = getenv("PG_ENC_TAIL_INORDER") == nullptr;
   hipStream_t se2 = st;
-  if (g_defer && g_defer_pending && g_side2) {
+  if (tail_side && g_defer && g_defer_pending && g_side2) {
     PG_CHECK_HIP(hipEventRecord(g_ev_fork, st));
     PG_CHECK_HIP(hipStreamWaitEvent(g_side2, g_ev_fork, 0));
     se2 = g_side2;
   }
-  T* oh = at<T>(ws, w.e_onehot);     // built by the forward pass (build_packed_kernel)
   float* dT = at<float>(ws, w.e_dT);
-  PG_CHECK_HIP(hipMemsetAsync(dT, 0, (size_t)Vp * 3 * Hq * 4, se2));
-  PG_TRY(launch_gemm_tn<T>(oh, Vp, dGI, 3 * Hq, Vp, 3 * Hq, (int)Ne, dT, 3 * Hq, 1.0f, nullptr, se2, nullptr, grads + po.enc_bih));
+  // (rows grouped by token in the forward pass, or here; partial sums in the encoder's own slab - the decoder's deferred GEMMs
+  // may still be using theirs.  More rows than one sort takes: several passes through the second side stream's slab buffer,
+  // behind the join with that stream.)
+  bool sorted = tok_sorted(ws, 1);
+  if (!sorted && Ne <= tok_sort_max_rows(Vp)) {
+    PG_TRY(launch_tok_sort(at<int>(ws, w.enc_tok), Ne, Vp, tok_sort_at(ws, w.e_ts), se2));
+    sorted = true;
+  }
+  if (sorted) {
+    PG_TRY(launch_tok_sum_sorted<T>(dGI, 3 * Hq, Ne, 3 * Hq, Vp, tok_sort_at(ws, w.e_ts), at<float>(ws, w.e_slab),
+                                    (size_t)tok_sort_chunks(Ne, Vp) * 3 * Hq * sizeof(float), dT, grads + po.enc_bih, 0, se2));
+  } else {
+    if (se2 == st) PG_TRY(defer_join(st, false));
+    PG_TRY(launch_tok_scatter_sum<T>(at<int>(ws, w.enc_tok), dGI, 3 * Hq, Ne, 3 * Hq, Vp, dT, grads + po.enc_bih,
+                                     at<char>(ws, w.b_slab[1]), PG_TN_SLAB_BYTES, se2));
+  }
   PG_TRY(small_gemm(dT, 3 * Hq, 1, params + po.enc_wih, E, 1, V, E, 3 * Hq, grads + po.x_emb, E, d->pad, se2));
   PG_TRY(small_gemm(dT, 1, 3 * Hq, params + po.x_emb, E, 1, 3 * Hq, E, V, grads + po.enc_wih, E, -1, se2));
-  if (se2 != st) PG_CHECK_HIP(hipEventRecord(g_ev_join2, g_side2));   // the joins below and later wait for this newer record
+  if (se2 != st) PG_TRY(defer_rerecord());   // the joins below and later wait for this newer record
   PG_TRY(launch_gemm_tn<T>(dGH, 3 * Hq, at<T>(ws, w.e_sv[4]), Hq, 3 * Hq, Hq, (int)Ne, grads + po.enc_whh, Hq, 1.0f, nullptr, st,
                            grads + po.enc_bhh));
   PG_TRY(defer_join(st, false));   // the decoder's deferred weight gradients: complete in stream order from here on
@@ -1039,6 +1115,7 @@ extern "C" int pg_encoder_bwd(const pg_dims* d, int dtype, const float* params, 
   PG_REQUIRE(params && shadow && ws && grads, "pg_encoder_bwd: NULL buffer");
   PG_REQUIRE(!enc_generic(d), "pg_encoder_bwd serves the one-layer one-direction encoder; Lq=%d qbidir=%d goes to pg_encoder_gen_bwd",
              d->Lq, d->qbidir);
+  PG_TRY(shadow_join((hipStream_t)stream));   // (the forward pass's token sort may have run on the side stream)
   return dtype == PG_BF16 ? encoder_bwd_t<bf16_t>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, h_lengths, dp, dz, g_host, g_dev,
                                                   grads, (hipStream_t)stream)
                           : encoder_bwd_t<float>(d, dtype, params, shadow, ws, ws_bytes, B, Tmax, h_lengths, dp, dz, g_host, g_dev,

@@ -1,10 +1,11 @@
 #!/bin/bash
-# A/B of one environment switch on the training step: tools/ab_env.sh VAR=VALUE   (run through gpurun from the repo root)
+# A/B of environment switches on the training step (run through gpurun from the repo root):
+#   bash tools/ab_env.sh "" "PG_TAIL_FORK_LATE=1" ...   -> ms_per_step of a short bench run under each setting
 set -e
-run() { timeout -k 10 200 python bench.py --steps 30 --warmup 5 --no_cpu_baseline --no_e2e --no_proxy --sample_n 0 | python -c "
-import sys,json
-d=json.loads(sys.stdin.readlines()[-1]); r=d['roofline']
-print('%s ms/step %.3f  bwd %.1f us  fwd %.1f us  losses %s' % (sys.argv[1], d['ms_per_step'], r['avg_launch_us'], r['fwd_recurrence']['avg_launch_us'], d['last_losses']))" "$1"; }
-run base
-env "$1" bash -c "$(declare -f run); run '$1'"
-run base2
+R=$PWD; O=$R/gpurun_out
+: > $O/ab_env.txt
+for e in "$@"; do
+  line=$(env $e timeout -k 10 120 python3 $R/bench.py --steps 40 --warmup 10 --no_cpu_baseline --no_e2e --no_proxy --no_roofline --sample_n 0 --no_configs0 2>/dev/null | tail -1)
+  echo "[$e] $(echo "$line" | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], d["value"])')" >> $O/ab_env.txt
+done
+cat $O/ab_env.txt
