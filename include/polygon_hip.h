@@ -212,6 +212,15 @@ PG_API int pg_gemm_tn(int dtype, const void* A, long lda, const void* B, long ld
 PG_API int pg_gemm_tn_ws(int dtype, const void* A, long lda, const void* B, long ldb, int M, int N, int R, float* C, long ldc,
                          float alpha, float* colsum_a, float* colsum_b, float* slab, size_t slab_bytes, void* stream);
 
+/* pg_tok_scatter_sum: the gradient of a gather table (the embedding folded into the layer-0 input projection): dT[v, 0..C) =
+ * sum of G[r, 0..C) over the rows r with tok[r] = v, v < Vp <= 128 (rows with a token outside [0, Vp) are left out), and
+ * colsum[c] (nullable) += the sum over all those rows.  G: [N, ldg] in dtype, 16-byte aligned rows, C a multiple of
+ * 16 / sizeof(dtype).  scratch: 256-byte aligned; pg_tok_scatter_scratch_bytes(N, C, Vp) bytes take the rows in one pass, less
+ * (down to the bytes of a 128-row pass) takes them in several.  dT is overwritten, not accumulated into. */
+PG_API size_t pg_tok_scatter_scratch_bytes(long N, int C, int Vp);
+PG_API int pg_tok_scatter_sum(int dtype, const int32_t* tok, const void* G, long ldg, long N, int C, int Vp, float* dT,
+                              float* colsum, void* scratch, size_t scratch_bytes, void* stream);
+
 /* pg_bench_gru: launches one recurrent step kernel (which = 0 forward cell, 1 backward cell) `repeat` times on
  * scratch operands carved from ws (>= 64*rows*H bytes + 16*H*H bytes): used by bench.py to time the dominant kernel
  * with HIP events, and by the kernel-tuning scripts under tools/. */

@@ -1,6 +1,7 @@
 // C-ABI entry points that expose single kernels for unit tests (tests/test_gpu_kernels.py).
 #include "../../include/polygon_hip.h"
 #include "pg_gemm.h"
+#include "pg_scatter.h"
 
 template <typename T>
 static int gemm_nt_t(const void* A, long lda, const void* B, long ldb, int M, int N, int K, const float* bias,
@@ -80,4 +81,18 @@ static int bench_gru_t(int which, int rows, int H, void* ws, size_t ws_bytes, in
 extern "C" int pg_bench_gru(int dtype, int which, int rows, int H, void* ws, size_t ws_bytes, int repeat, void* stream) {
   if (dtype == PG_BF16) return bench_gru_t<bf16_t>(which, rows, H, ws, ws_bytes, repeat, (hipStream_t)stream);
   return bench_gru_t<float>(which, rows, H, ws, ws_bytes, repeat, (hipStream_t)stream);
+}
+
+// the embedding-table gradient (pg_scatter.h): sort by token + per-chunk sums + reduce, in one or several passes
+extern "C" size_t pg_tok_scatter_scratch_bytes(long N, int C, int Vp) {
+  if (N < 1 || C < 1 || Vp < 1 || Vp > PG_TS_MAX_VP) return 0;
+  return tok_scatter_layout(std::min(N, tok_sort_max_rows(Vp)), C, Vp).total;
+}
+extern "C" int pg_tok_scatter_sum(int dtype, const int32_t* tok, const void* G, long ldg, long N, int C, int Vp, float* dT,
+                                  float* colsum, void* scratch, size_t scratch_bytes, void* stream) {
+  if (dtype == PG_F32)
+    return launch_tok_scatter_sum<float>(tok, (const float*)G, ldg, N, C, Vp, dT, colsum, scratch, scratch_bytes, (hipStream_t)stream);
+  if (dtype == PG_BF16)
+    return launch_tok_scatter_sum<bf16_t>(tok, (const bf16_t*)G, ldg, N, C, Vp, dT, colsum, scratch, scratch_bytes, (hipStream_t)stream);
+  PG_FAIL(PG_ERR_ARG, "pg_tok_scatter_sum: bad dtype %d", dtype);
 }

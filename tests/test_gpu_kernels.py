@@ -148,3 +148,76 @@ def test_gemm_tn_integer_exact():
         _lib.check(st)
         torch.cuda.synchronize()
         assert torch.equal(C.cpu().double(), ref), dt
+
+
+def _scatter_ref(tok, G, Vp):
+    dT = torch.zeros(Vp, G.shape[1], dtype=torch.float64)
+    ok = (tok >= 0) & (tok < Vp)
+    dT.index_add_(0, tok[ok].long(), G[ok].double())
+    return dT, G[ok].double().sum(0)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("case", [
+    # (rows, columns, row stride, Vp, scratch: 0 = one pass, else bytes -> several accumulating passes, skew)
+    (22000, 1536, 1536, 64, 0, True),      # decoder of the bench configuration
+    (333, 96, 104, 64, 0, True),           # fewer rows than a chunk for most tokens, padded rows, C not a multiple of 128
+    (1, 8, 8, 64, 0, False),               # one row
+    (5000, 768, 768, 128, 0, False),       # wide vocabulary: the 512-thread sort
+    (9000, 512, 512, 64, 200 << 10, True), # scratch for 3200 rows per pass: three accumulating passes
+    (300000, 32, 32, 64, 0, True),         # more rows than one sort launch takes (255 per thread): two passes
+])
+def test_tok_scatter_sum(dt, case):
+    """The embedding-table gradient (pg_scatter.h: counting sort of the rows by token, per-chunk sums in registers, reduce)
+    against an fp64 index_add of the same (rounded) rows; tokens outside [0, Vp) are left out; dT is overwritten."""
+    tdt, code, tol = DT[dt]
+    N, C, ldg, Vp, scratch_bytes, skew = case
+    g = torch.Generator(device="cpu").manual_seed(N + C)
+    tok = torch.randint(0, Vp, (N,), generator=g, dtype=torch.int32)
+    if skew:                                # a few symbols carry most rows, as in SMILES
+        r = torch.rand(N, generator=g)
+        tok = torch.where(r < 0.45, torch.full_like(tok, 3), torch.where(r < 0.65, torch.full_like(tok, 4), tok))
+    if N > 100:
+        tok[7] = -1; tok[11] = Vp           # out of range: skipped
+    Gfull = torch.randn(N, ldg, generator=g).to(tdt)
+    L = _lib.lib()
+    L.pg_tok_scatter_scratch_bytes.restype = ctypes.c_size_t
+    need = L.pg_tok_scatter_scratch_bytes(ctypes.c_long(N), C, Vp)
+    assert need > 0
+    nbytes = scratch_bytes if scratch_bytes else need
+    assert nbytes <= need
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    tok_d, G_d = tok.cuda(), Gfull.cuda()
+    dT = torch.full((Vp, C), float("nan"), device="cuda")
+    cs = torch.full((C,), 2.0, device="cuda")
+    st = L.pg_tok_scatter_sum(code, _lib.ptr(tok_d), _lib.ptr(G_d), ctypes.c_long(ldg), ctypes.c_long(N), C, Vp, _lib.ptr(dT),
+                              _lib.ptr(cs), _lib.ptr(scratch), ctypes.c_size_t(nbytes), _lib.stream_ptr())
+    _lib.check(st, "pg_tok_scatter_sum")
+    torch.cuda.synchronize()
+    ref, ref_cs = _scatter_ref(tok, Gfull[:, :C].float(), Vp)
+    scale = max(ref.abs().max().item(), 1.0)
+    assert (dT.double().cpu() - ref).abs().max().item() <= 1e-5 * scale      # fp32 sums of exactly representable rows
+    assert (cs.double().cpu() - 2.0 - ref_cs).abs().max().item() <= 1e-5 * max(ref_cs.abs().max().item(), 1.0) * 4
+    # deterministic: the same call again gives the same bits
+    dT2 = torch.empty_like(dT)
+    st = L.pg_tok_scatter_sum(code, _lib.ptr(tok_d), _lib.ptr(G_d), ctypes.c_long(ldg), ctypes.c_long(N), C, Vp, _lib.ptr(dT2),
+                              None, _lib.ptr(scratch), ctypes.c_size_t(nbytes), _lib.stream_ptr())
+    _lib.check(st, "pg_tok_scatter_sum")
+    torch.cuda.synchronize()
+    assert torch.equal(dT, dT2)
+
+
+def test_tok_scatter_sum_rejects_bad_arguments():
+    L = _lib.lib()
+    L.pg_tok_scatter_scratch_bytes.restype = ctypes.c_size_t
+    assert L.pg_tok_scatter_scratch_bytes(ctypes.c_long(100), 64, 129) == 0
+    tok = torch.zeros(100, dtype=torch.int32, device="cuda")
+    G = torch.zeros(100, 64, device="cuda")
+    dT = torch.zeros(64, 64, device="cuda")
+    small = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    st = L.pg_tok_scatter_sum(_lib.PG_F32, _lib.ptr(tok), _lib.ptr(G), ctypes.c_long(64), ctypes.c_long(100), 64, 64, _lib.ptr(dT),
+                              None, _lib.ptr(small), ctypes.c_size_t(1024), _lib.stream_ptr())
+    assert st == -1 and b"scratch too small" in L.pg_last_error()
+    st = L.pg_tok_scatter_sum(_lib.PG_F32, _lib.ptr(tok), _lib.ptr(G), ctypes.c_long(64), ctypes.c_long(100), 62, 64, _lib.ptr(dT),
+                              None, _lib.ptr(small), ctypes.c_size_t(1024), _lib.stream_ptr())
+    assert st == -1
