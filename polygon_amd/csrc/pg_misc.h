@@ -297,10 +297,16 @@ static __global__ void colsum_kernel(const T* __restrict__ X, long R, int C, lon
 // per step, 110 us for 154 MB; this one streams).
 template <typename T>
 static __global__ __launch_bounds__(256) void rowseg_sum_kernel(const T* __restrict__ X, const int* __restrict__ off, int Tn, int C,
-                                                                 int B, float* __restrict__ out, T* __restrict__ out_op) {
+                                                                 int B, float* __restrict__ out, T* __restrict__ out_op,
+                                                                 float* __restrict__ zero, long n_zero) {
   constexpr int EPC = 16 / sizeof(T);
   __shared__ int soff[PG_MAX_T + 2];
   for (int i = threadIdx.x; i <= Tn; i += blockDim.x) soff[i] = off[i];
+  // (zero, optional: a buffer the NEXT kernels of the chain accumulate into - cleared here instead of by a memset between them)
+  if (zero)
+    for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < n_zero;
+         i += (long)gridDim.x * gridDim.y * blockDim.x)
+      zero[i] = 0.0f;
   __syncthreads();
   const int b = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int c = (blockIdx.x * 64 + (threadIdx.x & 63)) * EPC;
@@ -323,6 +329,13 @@ static __global__ __launch_bounds__(256) void rowseg_sum_kernel(const T* __restr
     for (int e = 0; e < EPC; ++e) s[e] += to_f32<T>(x[e]);
   };
   int t = 0;
+  for (; t + 8 <= len; t += 8) {                 // (8 loads in flight per thread: the chain of ~60 steps is latency-bound)
+    uint4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const uint4*>(X + (long)(soff[t + i] + b) * C + c);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) add(v[i]);
+  }
   for (; t + 4 <= len; t += 4) {
     uint4 v[4];
 #pragma unroll

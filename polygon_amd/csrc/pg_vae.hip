@@ -915,11 +915,10 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   T* dh0_op = at<T>(ws, w.b_dh0_op);
   auto dz_chain = [&]() -> int {
     hipLaunchKernelGGL(rowseg_sum_kernel<T>, dim3(cdiv(3 * Hd, 64 * (16 / (int)sizeof(T))), cdiv(B, 4)), dim3(256), 0, st, dGI0,
-                       at<int>(ws, w.dec_off), sd.T, 3 * Hd, B, dzp, dzp_op);
+                       at<int>(ws, w.dec_off), sd.T, 3 * Hd, B, dzp, dzp_op, dz, (long)B * Dz);   // (also zeroes dz for the split-K GEMMs below)
     PG_CHECK_LAUNCH();
     if (!persist) PG_TRY(convert_to<T>(dh0, dh0_op, (long)B * Hd, st));
     // (K split over blocks: 8 output tiles with K = 1536 / 512 were 38 + 32 us of latency chain in front of the encoder BPTT)
-    PG_CHECK_HIP(hipMemsetAsync(dz, 0, (size_t)B * Dz * sizeof(float), st));
     PG_TRY(launch_gemm_nt_splitk<T>(dzp_op, 3 * Hd, at<T>(shadow, so.wih0zT), 3 * Hd, B, Dz, 3 * Hd, dz, Dz, 1.0f, st));
     PG_TRY(launch_gemm_nt_splitk<T>(dh0_op, Hd, at<T>(shadow, so.lat_wT), Hd, B, Dz, Hd, dz, Dz, 1.0f, st));
     return PG_OK;
