@@ -423,6 +423,25 @@ int launch_gemm_nt_splitk(const T* A, long lda, const T* B, long ldb, int M, int
   PG_REQUIRE(K % EPC == 0 && lda % EPC == 0 && ldb % EPC == 0, "gemm_nt_splitk: K/lda/ldb (%d,%ld,%ld) must be multiples of %d",
              K, lda, ldb, EPC);
   PG_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && C, "gemm_nt_splitk: operands must be 16-byte aligned");
+  // Two tilings.  These GEMMs sit on the chain between the decoder BPTT and the encoder BPTT while the 256 x 256 weight-gradient
+  // kernels hold every CU (one 128-KB workgroup each, 2 x 192 of them queued): a 128 x 128 block wants 73 KB of LDS, finds none
+  // beside them and waits for a CU to come free (15 us alone, up to 80 us in the step).  64 x 64 tiles with 32-element K
+  // steps (PG_SPLITK_TILE=64) take 20 KB and 48 registers, fit BESIDE a resident 256 x 256 workgroup and run in 13 + 11 us
+  // there - but the wait then falls to the next LDS-heavy kernel of the chain and the step is unchanged (measured), so the
+  // default stays the larger tile.
+  static const int tile_env = getenv("PG_SPLITK_TILE") ? atoi(getenv("PG_SPLITK_TILE")) : 0;
+  const bool small = tile_env == 64;
+  if (small) {
+    using Cfg = TileCfg<T, 64, 64, 4, 2, 2>;
+    const int tiles = cdiv(M, Cfg::BM) * cdiv(N, Cfg::BN), nkt = cdiv(K, Cfg::BK);
+    int splits = max(1, min(nkt / 2, 256 / max(1, tiles)));
+    const int kt_per_split = cdiv(nkt, splits);
+    splits = cdiv(nkt, kt_per_split);
+    PG_LAUNCH_BIG_SMEM(gemm_nt_splitk_kernel<Cfg>, dim3(tiles * splits), dim3(Cfg::NTHREADS), Cfg::SMEM_BYTES, stream, A, lda, B,
+                       ldb, M, N, K, kt_per_split, C, ldc, alpha);
+    PG_CHECK_LAUNCH();
+    return PG_OK;
+  }
   using Cfg = TileCfg<T, 128, 128, 8, 2, 2>;
   const int tiles = cdiv(M, Cfg::BM) * cdiv(N, Cfg::BN), nkt = cdiv(K, Cfg::BK);
   // about one block per CU, at least 2 K tiles per block

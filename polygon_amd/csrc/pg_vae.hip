@@ -1029,8 +1029,17 @@ static int encoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
                      at<float>(ws, w.e_eps), dz, g_host * inv_B, g_dev, B, Dz, dq, dq_op);
   PG_CHECK_LAUNCH();
   const T* hfin = at<T>(ws, w.e_hfin_op);
-  PG_TRY(launch_gemm_tn<T>(dq_op, 2 * Dz, hfin, Hq, Dz, Hq, B, grads + po.qmu_w, Hq, 1.0f, nullptr, st, grads + po.qmu_b));
-  PG_TRY(launch_gemm_tn<T>(dq_op + Dz, 2 * Dz, hfin, Hq, Dz, Hq, B, grads + po.qlv_w, Hq, 1.0f, nullptr, st, grads + po.qlv_b));
+  // The q heads' weight gradients feed nothing downstream, and in front of the recurrence they sit in the window in which the
+  // decoder's 256 x 256 weight-gradient workgroups hold every CU's LDS (the first of them waits ~50 us for a CU).  Moving
+  // them behind the recurrence (PG_QGRAD_LATE=1, end of the embedding tail's stream) only hands the wait to the next
+  // LDS-heavy kernel of the chain, and the recurrence then ends while the side streams' last GEMMs still run: +0.02 ms.
+  static const bool qgrad_early = getenv("PG_QGRAD_LATE") == nullptr;
+  auto q_grads = [&](hipStream_t sq) -> int {
+    PG_TRY(launch_gemm_tn<T>(dq_op, 2 * Dz, hfin, Hq, Dz, Hq, B, grads + po.qmu_w, Hq, 1.0f, nullptr, sq, grads + po.qmu_b));
+    PG_TRY(launch_gemm_tn<T>(dq_op + Dz, 2 * Dz, hfin, Hq, Dz, Hq, B, grads + po.qlv_w, Hq, 1.0f, nullptr, sq, grads + po.qlv_b));
+    return PG_OK;
+  };
+  if (qgrad_early) PG_TRY(q_grads(st));
   float* dhfin = at<float>(ws, w.b_dhfin);
   {
     GemmEpi<T> e;
@@ -1099,6 +1108,7 @@ static int encoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   }
   PG_TRY(small_gemm(dT, 3 * Hq, 1, params + po.enc_wih, E, 1, V, E, 3 * Hq, grads + po.x_emb, E, d->pad, se2));
   PG_TRY(small_gemm(dT, 1, 3 * Hq, params + po.x_emb, E, 1, 3 * Hq, E, V, grads + po.enc_wih, E, -1, se2));
+  if (!qgrad_early) PG_TRY(q_grads(se2));    // (behind the embedding tail: the shorter of the two chains that end the step)
   if (se2 != st) PG_TRY(defer_rerecord());   // the joins below and later wait for this newer record
   PG_TRY(launch_gemm_tn<T>(dGH, 3 * Hq, at<T>(ws, w.e_sv[4]), Hq, 3 * Hq, Hq, (int)Ne, grads + po.enc_whh, Hq, 1.0f, nullptr, st,
                            grads + po.enc_bhh));
