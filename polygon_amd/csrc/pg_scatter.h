@@ -1,8 +1,8 @@
 // Gradient of a gather table: dT[v, :] = sum of G[r, :] over the packed rows r with tok[r] = v (x_emb folded into the layer-0
 // input projection, pg_misc.h gi_table_kernel; reference: the nn.Embedding + nn.GRU input of vae_model.py:70-96).
 //
-// A scatter-sum, HBM-bound (G is read once), not a GEMM.  What was measured on the decoder's shape (22 k rows x 1536 columns
-// bf16, 64-row table; tools/scatter_bench.hip):
+// A scatter-sum, HBM-bound (G is read once), not a GEMM.  What was measured on tools/scatter_bench.hip's shape (22 k rows x
+// 1536 columns bf16, 64-row table, SMILES-like token skew; the decoder of the bench step has ~49 k rows):
 //   one-hot^T . G on the MFMA engine (rounds 1-3)                       83 us in the step (half-empty 128-row tiles, a one-hot
 //                                                                       operand per column tile)
 //   LDS table per block, ds_add_f32                                     180 us: LDS float atomics retire ~1 lane per 3 clocks
