@@ -14,14 +14,15 @@
  *
  * Library-owned state (process-wide, NOT thread-safe: one process per GPU, one calling thread at a
  * time is the model): (1) a 64-byte device word + 64-byte pinned host mirror "a persistent kernel
- * gave up", allocated on the first persistent launch and never freed; (2) the TWO side streams and four
- * events (fork, two joins, shadow rebuild) of pg_defer_weight_grads, created on first use; (3) up to
+ * gave up", allocated on the first persistent launch and never freed; (2) the TWO side streams and five
+ * events (fork, two joins, shadow rebuild, tokens packed) of pg_defer_weight_grads, created on first use; (3) up to
  * 2 x 512 HIP event pairs while pg_profile_enable is on; (4) the switches set by pg_persist_disable /
  * pg_defer_weight_grads / pg_profile_enable / pg_persist_spin_limit / pg_entry_checks (PG_NO_PERSIST is
  * read once at first use) - process-global and NOT thread-safe: the Python layer toggles
  * pg_defer_weight_grads around every training step, so two threads must not drive one process's
  * library at once; (5) the 2-KiB static device array of pg_clip_adam_static; (6) a 64-entry host table
- * "layout of the saved activations per workspace" (pg_decoder_fwd -> pg_decoder_bwd).  Nothing else
+ * "layout of the saved activations per workspace" (pg_decoder_fwd -> pg_decoder_bwd) and two 8-entry ones
+ * ("BPTT counters still cleared", "rows grouped by token") written by the forward calls for the backward calls.  Nothing else
  * persists between calls.
  *
  * Parameters are ONE flat fp32 buffer in the order of model.vae.parameters()
@@ -51,7 +52,7 @@ extern "C" {
 #define PG_MAX_T 511  /* longest sequence (bos..eos) the packed scheduler accepts */
 #define PG_MAX_ENC_LAYERS 4 /* q_n_layers limit of the generic encoder */
 #define PG_MAX_V 128  /* vocabulary limit of the softmax / cross-entropy / draw kernels */
-/* Padded vocabulary width Vp of the logits, probabilities and one-hot rows: 64 for V <= 64, else 128.  V <= 64 (the
+/* Padded vocabulary width Vp of the logits, probabilities and gather tables: 64 for V <= 64, else 128.  V <= 64 (the
  * reference's alphabet has 51 symbols) is the tuned case: fused projection + cross entropy, one-launch sampler; above it
  * the projection is a plain GEMM, the cross entropy and the draw take two vocabulary entries per lane, and pg_sample
  * runs the per-step kernels. */
@@ -242,15 +243,22 @@ PG_API int pg_profile_read(int which, double* total_ms, long* launches, double* 
  * the following pg_encoder_bwd, a latency-bound kernel on a quarter of the CUs.  The decoder weight gradients are
  * complete, in the order of the caller's stream, after the next pg_encoder_bwd or pg_clip_adam on that stream, or after
  * pg_deferred_join(stream) (e.g. the stream a gradient all-reduce will run on).  A caller that reads the gradients
- * without any of the three must leave this off.  pg_defer_weight_grads returns the previous setting (on < 0: query). */
+ * without any of the three must leave this off.  While on, the forward calls use the first side stream too:
+ * pg_prepare_weights rebuilds the decoder's shadow weights there, and when pg_encoder_fwd and pg_decoder_fwd follow it with
+ * the SAME tokens pointer and workspace, the encoder's token sort and the decoder's packing + token sort run there beside the
+ * encoder recurrence (ordered behind an event that pg_encoder_fwd records on the caller's stream once the tokens are packed,
+ * joined into the caller's stream by pg_decoder_fwd / pg_encoder_bwd); any other call order is served on the caller's stream.
+ * pg_defer_weight_grads returns the previous setting (on < 0: query). */
 PG_API int pg_defer_weight_grads(int on);
 PG_API int pg_deferred_join(void* stream);
 
 /* Failure of a persistent recurrence kernel (no reference counterpart).  The group-persistent kernels' workgroups wait
  * for each other; every wait is bounded (pg_persist_spin_limit polls, default 2^21 = 2-4 s), and a workgroup that gives up
  * sets a sticky device word.  Device side: pg_clip_adam's kernel reads the word and SKIPS the update, so garbage
- * gradients never reach the weights.  Host side: every entry point checks the word's pinned mirror on entry and
- * pg_check_failure(stream) synchronises `stream` first (call it before trusting or saving results).  The call that
+ * gradients never reach the weights.  Host side: the word is copied to its pinned mirror behind every persistent launch -
+ * in a training step (pg_decoder_fwd with save_for_backward, then pg_decoder_bwd) ONCE, at the end of pg_decoder_bwd - and
+ * every entry point checks the mirror on entry (an early warning); pg_check_failure(stream) synchronises `stream` and reads
+ * the device word itself (call it before trusting or saving results).  The call that
  * detects a failure returns PG_ERR_PERSIST once; the library then clears the word and switches every recurrence to the
  * per-step kernels (as pg_persist_disable(15)), so later calls work.  pg_persist_spin_limit(limit) sets the poll bound and
  * returns the previous one (limit < 0: query; 0 makes every unsatisfied wait give up at once - the test hook). */
