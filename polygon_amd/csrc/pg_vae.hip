@@ -613,7 +613,8 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
   // weights of this step are being rebuilt on the library's side stream (pg_prepare_weights under deferral, beside the
   // encoder forward), they go there too, behind the shadows, and the caller's stream picks both up with the ONE event wait
   // it owes anyway - 12 us of launches and a second wait off the stretch between the two forward recurrences.  (Not while
-  // deferred gradient GEMMs of an earlier micro-batch may still read this workspace's one-hot rows: g_defer_pending.)
+  // the deferred tail of an earlier micro-batch may still read this workspace's packed tokens and token tables on the second
+  // side stream: g_defer_pending.)
   const bool side_pro = g_shadow_pending && g_side && !g_defer_pending && g_tok_ptr == d_tokens && g_tok_ws == ws;
   g_tok_ptr = nullptr;
   hipStream_t pro = side_pro ? g_side : st;
