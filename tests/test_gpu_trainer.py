@@ -215,3 +215,40 @@ def test_adam_leaves_the_gradient_buffer_zeroed_and_the_engine_knows():
     torch.cuda.synchronize()
     ref = got.clone()                                             # parameters moved by two updates of lr 1e-3: close, not equal
     assert rel_err(opt.flat_grad, ref) <= 0.2, rel_err(opt.flat_grad, ref)     # (a buffer left at 3.0 + gradient would be off by orders of magnitude)
+
+
+def test_side_stream_prologue_and_token_sort_follow_changing_batches():
+    """The fused step under deferral packs the decoder's batch, clears its counters and sorts the rows by token on the
+    library's side stream, beside the encoder forward (pg_vae.hip: note_tokens / side_pro).  Batches that change size and
+    content from step to step (new workspace, new tokens behind the same entry points) must give the gradients of the
+    same step run entirely in order (deferral off: everything on the caller's stream, the rows sorted in the backward
+    pass).  Differences are the split-K atomics' summation order only."""
+    import ctypes
+    from polygon_amd import _lib
+    from polygon_amd.vae.vae_trainer import FusedClipAdam
+    L = _lib.lib()
+    model, _ = build_model(REAL, 11, "bf16", d_dropout=0.2)
+    model.train()
+    eng = model._engine
+    opt = FusedClipAdam(model, lr=1e-3)
+    ref_grad = torch.zeros_like(opt.flat_grad)
+    for step, (n, seed) in enumerate([(300, 1), (300, 2), (64, 3), (700, 4), (300, 5)]):
+        batch = model.get_collate_fn()(list(O.synthetic_smiles(n, seed=seed)))
+        eps = torch.from_numpy(np.random.default_rng(seed).standard_normal((n, REAL["Dz"])).astype(np.float32)).cuda()
+        # the shipped path first: the weights changed in the last opt.step(), so this call rebuilds the shadows on the side
+        # stream and the prologue + sorts follow them there
+        kl1, rec1 = eng.train_step(batch, 0.3, opt.flat_grad, eps=eps, p_drop=0.2, seed=77 + step)
+        torch.cuda.synchronize()
+        # in order, on the same weights (the shadows are current: nothing is pending on the side stream)
+        ref_grad.zero_()
+        old = L.pg_defer_weight_grads(0)
+        try:
+            kl0, rec0 = eng._train_step(batch, 0.3, ref_grad, eps, None, 0.2, 77 + step, None, 0.0, 0)
+        finally:
+            L.pg_defer_weight_grads(old)
+        torch.cuda.synchronize()
+        assert abs(kl0.item() - kl1.item()) <= 1e-5 * abs(kl0.item()) and abs(rec0.item() - rec1.item()) <= 1e-5 * abs(rec0.item())
+        err = ((opt.flat_grad - ref_grad).abs().max() / ref_grad.abs().max()).item()
+        assert err <= 2e-3, (step, err)
+        opt.step()                                   # new weights: the next step rebuilds the shadows on the side stream
+    _lib.check(L.pg_check_failure(_lib.stream_ptr()), "steps")
