@@ -438,7 +438,8 @@ static int encoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
   // there (an event behind the packing kernel, which the side stream waits for; the join is the one the decoder forward
   // owes anyway, re-recorded behind the sort), else in order.
   PG_TRY(note_tokens(d_tokens, ws, st));
-  const bool sort_now = save && Ne <= tok_sort_max_rows(vpad(d));
+  static const bool sort_in_bwd = getenv("PG_SORT_IN_BWD") != nullptr;   // A/B aid: leave the sort to the backward pass
+  const bool sort_now = save && !sort_in_bwd && Ne <= tok_sort_max_rows(vpad(d));
   if (sort_now) {
     hipStream_t ss = g_tok_ptr ? g_side : st;
     PG_TRY(launch_tok_sort(at<int>(ws, w.enc_tok), Ne, vpad(d), tok_sort_at(ws, w.e_ts), ss));
@@ -630,7 +631,8 @@ static int decoder_fwd_t(const pg_dims* d, int dtype, const float* params, const
   PG_CHECK_LAUNCH();
   bwd_sync_record(ws, true);
   // the rows grouped by token, for the embedding-table gradient of the backward pass: needs the tokens only
-  const bool sort_now = save && Nd <= tok_sort_max_rows(Vp);
+  static const bool sort_in_bwd = getenv("PG_SORT_IN_BWD") != nullptr;   // A/B aid: leave the sort to the backward pass
+  const bool sort_now = save && !sort_in_bwd && Nd <= tok_sort_max_rows(Vp);
   if (sort_now) PG_TRY(launch_tok_sort(at<int>(ws, w.dec_tok), Nd, Vp, tok_sort_at(ws, w.d_ts), pro));
   tok_sorted_set(ws, 2, sort_now);
   if (pro != st) PG_CHECK_HIP(hipEventRecord(g_ev_shadow, pro));               // (re-recorded behind the prologue)
