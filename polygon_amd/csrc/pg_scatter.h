@@ -25,7 +25,9 @@
   } while (0)
 #endif
 
-#define PG_TS_ROWS 128          // rows per chunk = 16 row lanes x 8 loads in flight per lane
+#ifndef PG_TS_ROWS
+#define PG_TS_ROWS 128          // rows per chunk = 16 row lanes x 8 loads in flight per lane (a multiple of 128)
+#endif
 #define PG_TS_MAX_VP 128
 
 struct TokScatterWs {

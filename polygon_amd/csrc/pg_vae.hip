@@ -395,7 +395,7 @@ static bool tok_sorted(const void* ws, int bit) {
     if (r.ws == ws) return (r.mask & bit) != 0;
   return false;
 }
-static_assert(PG_TS_ROWS == 128, "TrainWs::d_ts / e_ts are sized for 128-row chunks (pg_layout.h)");
+static_assert(PG_TS_ROWS >= 128 && PG_TS_ROWS % 128 == 0, "TrainWs::d_ts / e_ts / e_slab are sized for chunks of at least 128 rows (pg_layout.h)");
 static TokSort tok_sort_at(void* ws, const size_t (&o)[3]) {
   TokSort ts;
   ts.perm = at<int>(ws, o[0]); ts.chunks = at<int4>(ws, o[1]); ts.tokchunk = at<int>(ws, o[2]);
