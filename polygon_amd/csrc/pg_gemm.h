@@ -44,3 +44,6 @@ constexpr size_t PG_TN_SLAB_BYTES = (size_t)776 * 128 * 128 * sizeof(float);   /
 template <typename T>
 int launch_gemm_nt_splitk(const T* A, long lda, const T* B, long ldb, int M, int N, int K, float* C, long ldc, float alpha,
                           hipStream_t stream);
+
+// workgroups the next gemm_tn256 launches aim for (0: the default, 192); see decoder_bwd_t
+extern int g_tn256_blocks_hint;

@@ -485,6 +485,9 @@ static int launch_gemm_tn_cfg(const T* A, long lda, const T* B, long ldb, int M,
   return PG_OK;
 }
 
+// workgroups the next 256 x 256 launches aim for (0: the default); set around calls by pg_vae.hip, one calling thread
+int g_tn256_blocks_hint = 0;
+
 template <typename T>
 int launch_gemm_tn(const T* A, long lda, const T* B, long ldb, int M, int N, int R, float* C, long ldc, float alpha,
                    const float* alpha_dev, hipStream_t stream, float* colsum_a, float* colsum_b, float* partial,
@@ -505,7 +508,8 @@ int launch_gemm_tn(const T* A, long lda, const T* B, long ldb, int M, int N, int
     if (tn256 && partial && !alpha_dev && !colsum_a && !colsum_b && M % 256 == 0 && N % 256 == 0 && (M / 256) * (N / 256) >= 8) {
       const int tiles = (M / 256) * (N / 256);
       static const int blocks_env = getenv("PG_TN256_BLOCKS") ? atoi(getenv("PG_TN256_BLOCKS")) : 192;
-      int splits = max(1, blocks_env / tiles);
+      const int want = g_tn256_blocks_hint > 0 ? g_tn256_blocks_hint : blocks_env;
+      int splits = max(1, want / tiles);
       int rows_per_split = cdiv(cdiv(R, splits), 32) * 32;
       splits = cdiv(R, rows_per_split);
       if ((size_t)splits * tiles * 256 * 256 * sizeof(float) <= partial_bytes) {

@@ -937,7 +937,14 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
   int nbig = 0;
   // (each stream has its own slab buffer for the two-stage split-K reduction of these GEMMs)
   int which = 0;
-  auto big_stream = [&]() { which = (two && (nbig++ & 1)) ? 1 : 0; return which ? g_side2 : sg_big; };
+  // (PG_TN256_PAIR_BLOCKS, A/B aid: workgroups per GEMM for the four that run in pairs - 96 + 96 would leave the dz chain its
+  // 64 CUs; the fifth, which runs alone, keeps the default)
+  static const int pair_blocks = getenv("PG_TN256_PAIR_BLOCKS") ? atoi(getenv("PG_TN256_PAIR_BLOCKS")) : 0;
+  auto big_stream = [&]() {
+    g_tn256_blocks_hint = (two && nbig < 4) ? pair_blocks : 0;
+    which = (two && (nbig++ & 1)) ? 1 : 0;
+    return which ? g_side2 : sg_big;
+  };
   const bool slabs = !getenv("PG_TN_ATOMIC");
   hipStream_t sg = sg_big;
   PG_TRY(launch_gemm_tn<T>(dlog, Vp, top, Hd, V, Hd, (int)Nd, grads + po.fc_w, Hd, a_ce, s_ce, sg, grads + po.fc_b));   // decoder_fc
@@ -959,6 +966,7 @@ static int decoder_bwd_t(const pg_dims* d, int dtype, const float* params, const
                                PG_TN_SLAB_BYTES));
     }
   }
+  g_tn256_blocks_hint = 0;
   if (fork_early) {
     PG_TRY(dz_chain());
     // the small gradients below read the chain's outputs: the second side stream waits for it
